@@ -1,0 +1,567 @@
+// Graph-matching kernels for gfx950: node-similarity block, materialised
+// edge-similarity tensor, max-pool matching (MPM) streaming that tensor from HBM,
+// and the S-free fused MPM.  Compiled with -ffp-contract=off: every product and
+// sum below is a separately rounded fp32 operation, as on the reference's CPU path.
+#include "gvae_canonical.h"
+#include "gvae_common.h"
+
+namespace gvae {
+
+// ---------------------------------------------------------------------------
+// node similarity: NS[i,a] = 1 / (|degA[i] - degB[a]| + 1)
+// one work-group per graph; A then P are staged through LDS (padded rows) so the
+// per-row canonical sums read conflict-free.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_sim_kernel(const float *__restrict__ A,
+                                                       const float *__restrict__ P,
+                                                       const int32_t *__restrict__ Rarr, int ld,
+                                                       int64_t stride, float *__restrict__ NS) {
+  extern __shared__ float lds[];
+  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int R = Rarr[g];
+  if (R <= 0) return;
+  const int pad = R + 1;
+  float *tile = lds;                 // R * (R+1)
+  float *degA = lds + R * pad;       // R
+  float *degB = degA + R;            // R
+  const float *Ag = A + g * stride, *Pg = P + g * stride;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float *src = pass == 0 ? Ag : Pg;
+    for (int e = tid; e < R * R; e += nt) {
+      const int r = e / R, c = e - r * R;
+      tile[r * pad + c] = (r == c) ? 1.0f : src[(int64_t)r * ld + c];
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += nt) {
+      const float *row = tile + r * pad;
+      const float s = inner_row_sum([&](int k) { return row[k]; }, R);
+      (pass == 0 ? degA : degB)[r] = s;
+    }
+    __syncthreads();
+  }
+  float *NSg = NS + g * stride;
+  for (int e = tid; e < R * R; e += nt) {
+    const int i = e / R, a = e - i * R;
+    NSg[(int64_t)i * ld + a] = 1.0f / (fabsf(degA[i] - degB[a]) + 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// edge-similarity tensor, materialised.  One work-group per (graph, i): it owns the
+// contiguous slab S[i,:,:,:] (R^3 floats).  Each thread keeps its piece of P in
+// registers and sweeps j, so every store instruction of a wave covers one
+// contiguous run of the slab.  V = floats per lane per store (4 when R % 4 == 0).
+//   S[i,j,a,b] = A[i,j]*P[a,b]  (i != j, a != b);  NS[i,a] (i == j, a == b);  else 0
+// ---------------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ void edge_sim_body(const float *__restrict__ Pg,
+                                              const float *__restrict__ NSg, int ld, int R, int i,
+                                              float *__restrict__ slab, const float *arow) {
+  const int tid = threadIdx.x;
+  const int64_t R2 = (int64_t)R * R;
+
+  const int cols = R / V;                       // vector columns per row
+  const int lpr = cols < 256 ? cols : 256;      // lanes per row
+  const int rows_per_pass = 256 / lpr;
+  const int rslot = tid / lpr, c0 = tid - rslot * lpr;
+  if (rslot >= rows_per_pass) return;
+  for (int a = rslot; a < R; a += rows_per_pass) {
+    for (int c = c0; c < cols; c += lpr) {
+      float p[V], d[V];
+      const float nsv = NSg[(int64_t)i * ld + a];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int b = c * V + v;
+        p[v] = (b == a) ? 0.0f : Pg[(int64_t)a * ld + b];
+        d[v] = (b == a) ? nsv : 0.0f;
+      }
+      float *dst = slab + (int64_t)a * R + c * V;
+      for (int j = 0; j < R; ++j, dst += R2) {
+        const float aij = arow[j];
+        float o[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) o[v] = (j == i) ? d[v] : aij * p[v];
+        if constexpr (V == 4) {
+          *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else if constexpr (V == 2) {
+          *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+        } else {
+          dst[0] = o[0];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_sim_kernel(const float *__restrict__ A,
+                                                       const float *__restrict__ P,
+                                                       const float *__restrict__ NS,
+                                                       const int32_t *__restrict__ Rarr, int ld,
+                                                       int64_t stride, float *__restrict__ S,
+                                                       const int64_t *__restrict__ S_off) {
+  __shared__ float arow[1024];
+  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const int R = Rarr[g];
+  if (i >= R) return;
+  const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
+  float *slab = S + S_off[g] + (int64_t)i * R * R * R;
+  for (int j = tid; j < R; j += 256) arow[j] = (j == i) ? 1.0f : Ag[(int64_t)i * ld + j];
+  __syncthreads();
+  if ((R & 3) == 0) edge_sim_body<4>(Pg, NSg, ld, R, i, slab, arow);
+  else if ((R & 1) == 0) edge_sim_body<2>(Pg, NSg, ld, R, i, slab, arow);
+  else edge_sim_body<1>(Pg, NSg, ld, R, i, slab, arow);
+}
+
+// ---------------------------------------------------------------------------
+// MPM, one iteration, streaming S.  One work-group per (graph, i) reads the slab
+// S[i,:,:,:] exactly once:  T[j,a] = max_b S[i,j,a,b]*X[j,b]  (0 for j == i), then
+//   Xnew[i,a] = X[i,a]*S[i,i,a,a] + sum_j T[j,a]        (canonical column sum)
+// Each row (j,a) of R floats is spread over `lpr` = 2^lpr_log2 adjacent lanes, V
+// floats per lane per load, so a wave's load instruction covers 64/lpr consecutive
+// rows = one contiguous run of the slab.  The max over b is exact in any order.
+// ---------------------------------------------------------------------------
+template <int V>
+struct VecT;
+template <>
+struct VecT<4> { using type = float4; };
+template <>
+struct VecT<2> { using type = float2; };
+template <>
+struct VecT<1> { using type = float; };
+
+template <int V>
+__device__ __forceinline__ void vec_to_arr(const typename VecT<V>::type &v, float *o) {
+  if constexpr (V == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+  else if constexpr (V == 2) { o[0] = v.x; o[1] = v.y; }
+  else { o[0] = v; }
+}
+
+template <int V, int U>
+__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int i,
+                                              const float *Xs, float *T, float *nsrow) {
+  using vec_t = typename VecT<V>::type;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int R2 = R * R;
+  const int cols = R / V;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < cols && lpr_log2 < 6) ++lpr_log2;
+  const int lpr = 1 << lpr_log2;
+  const int lr = tid & (lpr - 1);
+  const int rows_per_pass = nt >> lpr_log2;
+  const int row0 = tid >> lpr_log2;
+
+  // (j,a) of this thread's first row; advanced incrementally, no division in the loop
+  int j = row0 / R, a = row0 - j * R;
+  const int dj = rows_per_pass / R, da = rows_per_pass - dj * R;
+
+  for (int row = row0; row < R2; row += rows_per_pass * U) {
+    float m[U];
+    int ju[U], au[U];
+    if (cols <= lpr) {
+      // single vector per lane per row: issue all U loads before any use
+      vec_t sv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ju[u] = j; au[u] = a;
+        const int r_u = row + u * rows_per_pass;
+        if (r_u < R2 && lr < cols)
+          sv[u] = *reinterpret_cast<const vec_t *>(slab + (int64_t)r_u * R + lr * V);
+        a += da; j += dj;
+        if (a >= R) { a -= R; ++j; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r_u = row + u * rows_per_pass;
+        float mm = -INFINITY;
+        if (r_u < R2 && lr < cols) {
+          float s[V];
+          vec_to_arr<V>(sv[u], s);
+          const float *xr = Xs + ju[u] * R + lr * V;
+#pragma unroll
+          for (int v = 0; v < V; ++v) mm = fmaxf(mm, s[v] * xr[v]);
+          if (ju[u] == i) {
+            const int bb = au[u] - lr * V;
+            if (bb >= 0 && bb < V) nsrow[au[u]] = s[bb];
+          }
+        }
+        m[u] = mm;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ju[u] = j; au[u] = a;
+        const int r_u = row + u * rows_per_pass;
+        float mm = -INFINITY;
+        if (r_u < R2) {
+          for (int c = lr; c < cols; c += lpr) {
+            float s[V];
+            vec_to_arr<V>(*reinterpret_cast<const vec_t *>(slab + (int64_t)r_u * R + c * V), s);
+            const float *xr = Xs + j * R + c * V;
+#pragma unroll
+            for (int v = 0; v < V; ++v) mm = fmaxf(mm, s[v] * xr[v]);
+            if (j == i) {
+              const int bb = a - c * V;
+              if (bb >= 0 && bb < V) nsrow[a] = s[bb];
+            }
+          }
+        }
+        m[u] = mm;
+        a += da; j += dj;
+        if (a >= R) { a -= R; ++j; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float mm = m[u];
+      for (int off = lpr >> 1; off > 0; off >>= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
+      const int r_u = row + u * rows_per_pass;
+      if (lr == 0 && r_u < R2) T[r_u] = (ju[u] == i) ? 0.0f : mm;
+    }
+  }
+}
+
+__global__ void mpm_stream_iter_kernel(const float *__restrict__ S,
+                                       const int64_t *__restrict__ S_off,
+                                       const int32_t *__restrict__ Rarr,
+                                       const float *__restrict__ X, int ldx, int64_t strideX,
+                                       float *__restrict__ Xnew, int64_t strideXnew,
+                                       const int32_t *__restrict__ flags) {
+  extern __shared__ float lds[];
+  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int R = Rarr[g];
+  if (i >= R || flags[g] != 0) return;
+  const int R2 = R * R;
+  float *Xs = lds;            // R*R
+  float *T = lds + R2;        // R*R
+  float *nsrow = T + R2;      // R
+  const float *Xg = X + g * strideX;
+  for (int e = tid; e < R2; e += nt) {
+    const int r = e / R, c = e - r * R;
+    Xs[e] = Xg[(int64_t)r * ldx + c];
+  }
+  __syncthreads();
+  const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
+  if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
+  else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
+  else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
+  __syncthreads();
+  float *Xn = Xnew + g * strideXnew;
+  for (int p = tid; p < R; p += nt) {
+    const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
+    Xn[i * R + p] = Xs[i * R + p] * nsrow[p] + et;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MPM normalise + convergence test, one work-group per graph.
+//   nrm = ||Xnew||_2 (canonical order);  X = Xnew / nrm;  converged if
+//   max|X - Xprev| < tol (fp32 compare) and early_stop.
+// The norm's eight fused chains are inherently serial; Xnew is staged through LDS
+// in tiles so the chain threads read it at LDS latency.
+// ---------------------------------------------------------------------------
+#define NORM_TILE 4096
+
+// chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
+__device__ __forceinline__ float norm_chain(const float *x, int n, int lane, float acc) {
+  int d = 0;
+  for (; d + 64 <= n; d += 64) {
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = x[d + 8 * t + lane];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc = __fmaf_rn(v[t], v[t], acc);
+  }
+  for (; d < n; d += 8) {
+    const float v = x[d + lane];
+    acc = __fmaf_rn(v, v, acc);
+  }
+  return acc;
+}
+
+// fold lanes 0..7 in order and fuse the tail (executed by the whole first wave)
+__device__ __forceinline__ float norm_finish(float acc, const float *tail, int ntail) {
+  float s = __shfl(acc, 0, 64);
+#pragma unroll
+  for (int l = 1; l < 8; ++l) s = s + __shfl(acc, l, 64);
+  for (int k = 0; k < ntail; ++k) s = __fmaf_rn(tail[k], tail[k], s);
+  return sqrtf(s);
+}
+
+__global__ __launch_bounds__(256) void mpm_stream_norm_kernel(
+    const float *__restrict__ Xnew, int64_t strideXnew, const int32_t *__restrict__ Rarr,
+    float *__restrict__ X, int ldx, int64_t strideX, float tol, int early_stop,
+    int32_t *__restrict__ flags, int32_t *__restrict__ iters_done) {
+  __shared__ float tile[NORM_TILE];
+  __shared__ float red[8];
+  __shared__ float s_nrm;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int R = Rarr[g];
+  if (R <= 0 || flags[g] != 0) return;
+  const int R2 = R * R;
+  const float *Xn = Xnew + g * strideXnew;
+  float *Xg = X + g * strideX;
+  const int n8 = R2 & ~7;
+  float acc = 0.f;
+  for (int base = 0; base < R2; base += NORM_TILE) {
+    const int n = min(NORM_TILE, R2 - base);
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) tile[e] = Xn[base + e];
+    __syncthreads();
+    if (tid < 64) {
+      const int nfull = min(n, n8 - base) > 0 ? min(n, n8 - base) : 0;
+      if (tid < 8) acc = norm_chain(tile, nfull, tid, acc);
+      if (base + n >= R2) {
+        const float nrm = norm_finish(acc, tile + nfull, n - nfull);
+        if (tid == 0) s_nrm = nrm;
+      }
+    }
+  }
+  __syncthreads();
+  const float nrm = s_nrm;
+  float dmax = 0.f;
+  bool isnan_any = false;
+  for (int e = tid; e < R2; e += 256) {
+    const int r = e / R, c = e - r * R;
+    const float v = Xn[e] / nrm;
+    const float d = fabsf(v - Xg[(int64_t)r * ldx + c]);
+    isnan_any |= (d != d);
+    dmax = fmaxf(dmax, d);
+    Xg[(int64_t)r * ldx + c] = v;
+  }
+  if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
+  for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = dmax;
+  __syncthreads();
+  if (tid == 0) {
+    dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    iters_done[g] += 1;
+    if (early_stop && dmax < tol) flags[g] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused S-free MPM: one work-group per graph, Pt (P transposed, zero diagonal),
+// X and M resident in LDS, A as a bit matrix.  Per iteration:
+//   M[j,a]  = max_b Pt[b,a]*X[j,b]                      (>= 0; Pt[a,a] = 0)
+//   Xn[i,a] = X[i,a]*NS[i,a] + sum_{j != i, A[i,j] != 0} M[j,a]   (canonical column sum,
+//             absent terms contribute an exact +0 at their position)
+//   X = Xn / ||Xn||_2 ; stop when max|X - Xprev| < tol
+// The previous X lives in the caller's d_X buffer (global), the new one in LDS.
+// ---------------------------------------------------------------------------
+__global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__restrict__ P,
+                                 const float *__restrict__ NS, const int32_t *__restrict__ Rarr,
+                                 int ld, int64_t stride, float *__restrict__ X, int ldx,
+                                 int64_t strideX, int iters, float tol, int early_stop,
+                                 int32_t *__restrict__ iters_done) {
+  extern __shared__ float lds[];
+  __shared__ float red[16];
+  __shared__ float s_nrm;
+  __shared__ int s_stop;
+  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int R = Rarr[g];
+  if (R <= 0) {
+    if (tid == 0) iters_done[g] = 0;
+    return;
+  }
+  const int R2 = R * R, W = (R + 31) >> 5;
+  float *Pt = lds;                 // R*R, Pt[b*R + a] = P[a,b], 0 on the diagonal
+  float *Xs = Pt + R2;             // R*R
+  float *M = Xs + R2;              // R*R
+  uint32_t *Abits = reinterpret_cast<uint32_t *>(M + R2);  // R*W
+  const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
+  float *Xg = X + g * strideX;
+
+  for (int e = tid; e < R2; e += nt) {
+    const int r = e / R, c = e - r * R;
+    Pt[c * R + r] = (r == c) ? 0.0f : Pg[(int64_t)r * ld + c];
+    Xs[e] = Xg[(int64_t)r * ldx + c];
+  }
+  for (int e = tid; e < R * W; e += nt) {
+    const int r = e / W, w = e - r * W;
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      const int c = w * 32 + k;
+      if (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) bits |= (1u << k);
+    }
+    Abits[e] = bits;
+  }
+  __syncthreads();
+
+  const int n8 = R2 & ~7;
+  int done = 0;
+  for (int it = 0; it < iters; ++it) {
+    // phase 1: M = maxprod(X, Pt)
+    for (int e = tid; e < R2; e += nt) {
+      const int j = e / R, a = e - j * R;
+      const float *xr = Xs + j * R;
+      const float *pc = Pt + a;
+      float m = 0.0f;
+      for (int b = 0; b < R; ++b) m = fmaxf(m, pc[b * R] * xr[b]);
+      M[e] = m;
+    }
+    __syncthreads();
+    // phase 2: Xn (written over Xs; the previous X stays in global memory)
+    for (int e = tid; e < R2; e += nt) {
+      const int i = e / R, a = e - i * R;
+      const uint32_t *ab = Abits + i * W;
+      const float et = column_sum(
+          [&](int jj) { return ((ab[jj >> 5] >> (jj & 31)) & 1u) ? M[jj * R + a] : 0.0f; }, a, R);
+      Xs[e] = Xs[e] * NSg[(int64_t)i * ld + a] + et;
+    }
+    __syncthreads();
+    // phase 3: canonical norm over the contiguous R*R block
+    if (tid < 64) {
+      float acc = 0.f;
+      if (tid < 8) acc = norm_chain(Xs, n8, tid, acc);
+      const float nrm = norm_finish(acc, Xs + n8, R2 - n8);
+      if (tid == 0) s_nrm = nrm;
+    }
+    __syncthreads();
+    const float nrm = s_nrm;
+    float dmax = 0.f;
+    bool isnan_any = false;
+    for (int e = tid; e < R2; e += nt) {
+      const int r = e / R, c = e - r * R;
+      const float v = Xs[e] / nrm;
+      const float d = fabsf(v - Xg[(int64_t)r * ldx + c]);
+      isnan_any |= (d != d);
+      dmax = fmaxf(dmax, d);
+      Xs[e] = v;
+      Xg[(int64_t)r * ldx + c] = v;
+    }
+    if (isnan_any) dmax = INFINITY;
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = dmax;
+    __syncthreads();
+    if (tid == 0) {
+      float d = red[0];
+      for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
+      s_stop = (early_stop && d < tol) ? 1 : 0;
+    }
+    __syncthreads();
+    ++done;
+    if (s_stop) break;
+  }
+  if (tid == 0) iters_done[g] = done;
+}
+
+__global__ void zero_i32_kernel(int32_t *a, int32_t *b, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    a[t] = 0;
+    b[t] = 0;
+  }
+}
+
+}  // namespace gvae
+
+using namespace gvae;
+
+extern "C" {
+
+int gvae_node_sim(const float *d_A, const float *d_P, const int32_t *d_R, int n_graphs, int ld,
+                  int64_t stride, float *d_NS, void *stream) {
+  GVAE_REQUIRE(d_A && d_P && d_R && d_NS, GVAE_EINVAL, "node_sim: null pointer");
+  GVAE_REQUIRE(n_graphs >= 0 && ld > 0 && stride >= (int64_t)ld * ld, GVAE_EINVAL,
+               "node_sim: bad sizes (n_graphs=%d ld=%d)", n_graphs, ld);
+  GVAE_REQUIRE(ld <= 192, GVAE_ELIMIT, "node_sim: ld=%d exceeds the LDS tile (192)", ld);
+  if (n_graphs == 0) return GVAE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * ((size_t)ld * (ld + 1) + 2 * ld);
+  ProfileScope ps(F_NODE_SIM, s);
+  hipLaunchKernelGGL(node_sim_kernel, dim3(n_graphs), dim3(256), lds, s, d_A, d_P, d_R, ld, stride,
+                     d_NS);
+  return check_launch("node_sim");
+}
+
+int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                  int n_graphs, int ld, int64_t stride, int r_max, float *d_S,
+                  const int64_t *d_S_off, void *stream) {
+  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_S && d_S_off, GVAE_EINVAL, "edge_sim: null pointer");
+  GVAE_REQUIRE(n_graphs >= 0 && ld > 0 && r_max > 0 && r_max <= ld && r_max <= 1024, GVAE_EINVAL,
+               "edge_sim: bad sizes (n_graphs=%d ld=%d r_max=%d)", n_graphs, ld, r_max);
+  GVAE_REQUIRE(((uintptr_t)d_S & 15) == 0, GVAE_EINVAL, "edge_sim: S must be 16-byte aligned");
+  GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "edge_sim: more than 65535 graphs per call");
+  if (n_graphs == 0) return GVAE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ProfileScope ps(F_EDGE_SIM, s);
+  hipLaunchKernelGGL(edge_sim_kernel, dim3(r_max, n_graphs), dim3(256), 0, s, d_A, d_P, d_NS, d_R,
+                     ld, stride, d_S, d_S_off);
+  return check_launch("edge_sim");
+}
+
+int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
+  // Xnew (n_graphs * ldx * ldx floats) + flags (n_graphs int32), 256-byte aligned parts
+  int64_t xb = ((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL;
+  int64_t fb = ((int64_t)n_graphs * 4 + 255) & ~255LL;
+  return xb + fb;
+}
+
+int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R, int n_graphs,
+                    int r_max, float *d_X, int ldx, int64_t strideX, int iters, float tol,
+                    int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+  GVAE_REQUIRE(d_S && d_S_off && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
+               "mpm_stream: null pointer");
+  GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
+               "mpm_stream: bad sizes (n_graphs=%d r_max=%d ldx=%d iters=%d)", n_graphs, r_max, ldx,
+               iters);
+  GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "mpm_stream: more than 65535 graphs per call");
+  const size_t lds = sizeof(float) * (2 * (size_t)r_max * r_max + r_max);
+  GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
+               lds);
+  if (n_graphs == 0) return GVAE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float *Xnew = (float *)d_ws;
+  const int64_t strideXnew = (int64_t)ldx * ldx;
+  int32_t *flags = (int32_t *)((char *)d_ws + (((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL));
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, flags,
+                     d_iters_done, n_graphs);
+  const int nt = r_max > 64 ? 1024 : 256;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_iter_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_stream: cannot reserve %zu bytes of LDS: %s",
+                 lds, hipGetErrorString(e));
+  }
+  for (int it = 0; it < iters; ++it) {
+    {
+      ProfileScope ps(F_MPM_ITER, s);
+      hipLaunchKernelGGL(mpm_stream_iter_kernel, dim3(r_max, n_graphs), dim3(nt), lds, s, d_S,
+                         d_S_off, d_R, d_X, ldx, strideX, Xnew, strideXnew, flags);
+    }
+    {
+      ProfileScope ps(F_MPM_NORM, s);
+      hipLaunchKernelGGL(mpm_stream_norm_kernel, dim3(n_graphs), dim3(256), 0, s, Xnew, strideXnew,
+                         d_R, d_X, ldx, strideX, tol, early_stop, flags, d_iters_done);
+    }
+  }
+  return check_launch("mpm_stream");
+}
+
+int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                   int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                   int64_t strideX, int iters, float tol, int early_stop, int32_t *d_iters_done,
+                   void *stream) {
+  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done, GVAE_EINVAL,
+               "mpm_fused: null pointer");
+  GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
+               "mpm_fused: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", n_graphs, r_max, ld, ldx);
+  const size_t lds = 12 * (size_t)r_max * r_max + 4 * (size_t)r_max * ((r_max + 31) / 32);
+  GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
+               "mpm_fused: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", r_max, lds);
+  if (n_graphs == 0) return GVAE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)mpm_fused_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_fused: cannot reserve %zu bytes of LDS: %s", lds,
+                 hipGetErrorString(e));
+  }
+  const int nt = r_max <= 32 ? 256 : (r_max <= 64 ? 512 : 1024);
+  ProfileScope ps(F_MPM_FUSED, s);
+  hipLaunchKernelGGL(mpm_fused_kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld,
+                     stride, d_X, ldx, strideX, iters, tol, early_stop, d_iters_done);
+  return check_launch("mpm_fused");
+}
+
+}  // extern "C"

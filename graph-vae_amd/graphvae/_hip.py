@@ -1,0 +1,175 @@
+"""ctypes binding of libgvae_hip.so (declared in include/gvae_hip.h).
+
+The library is the product path: if it is missing or a call fails this module
+raises; there is no CPU fallback.  torch is used only to own device memory and to
+supply the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libgvae_hip.so"
+_lib = None
+
+MAX_NODES_LDS = 128
+
+
+class GvaeHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise GvaeHipError(
+                f"{_LIB_PATH} not found: build it with `make -C graph-vae_amd/csrc` "
+                "(or __graft_entry__.build()); the GraphVAE HIP path has no fallback")
+        L = ctypes.CDLL(str(_LIB_PATH))
+        L.gvae_version.restype = c_int
+        L.gvae_last_error.restype = ctypes.c_char_p
+        L.gvae_profile_enable.argtypes = [c_int]
+        L.gvae_profile_read.argtypes = [c_int, POINTER(c_double), POINTER(c_int64)]
+        L.gvae_node_sim.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p,
+                                    c_void_p]
+        L.gvae_edge_sim.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                    c_int, c_void_p, c_void_p, c_void_p]
+        L.gvae_mpm_stream_ws_bytes.argtypes = [c_int, c_int]
+        L.gvae_mpm_stream_ws_bytes.restype = c_int64
+        L.gvae_mpm_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                      c_int64, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]
+        L.gvae_mpm_fused.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                     c_int, c_void_p, c_int, c_int64, c_int, c_float, c_int,
+                                     c_void_p, c_void_p]
+        L.gvae_lsap.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p, c_int,
+                                c_void_p, c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise GvaeHipError(f"libgvae_hip error {rc}: {lib().gvae_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
+    if not t.is_cuda:
+        raise GvaeHipError("expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise GvaeHipError(f"expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+# --------------------------------------------------------------------------- profiling
+FAMILIES = {"edge_sim": 0, "mpm_stream_iter": 1, "mpm_stream_norm": 2, "mpm_fused": 3, "lsap": 4,
+            "node_sim": 5}
+
+
+def profile_enable(on: bool) -> None:
+    _check(lib().gvae_profile_enable(int(on)))
+
+
+def profile_reset() -> None:
+    _check(lib().gvae_profile_reset())
+
+
+def profile_read(family: str):
+    ms, n = c_double(0.0), c_int64(0)
+    _check(lib().gvae_profile_read(FAMILIES[family], ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value
+
+
+# --------------------------------------------------------------------------- matching
+def node_sim(A: torch.Tensor, P: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+    """A, P: (G, N, N) fp32; R: (G,) int32.  Returns NS (G, N, N)."""
+    _dev(A, torch.float32), _dev(P, torch.float32), _dev(R, torch.int32)
+    G, N, _ = A.shape
+    NS = torch.zeros_like(A)
+    _check(lib().gvae_node_sim(A.data_ptr(), P.data_ptr(), R.data_ptr(), G, N, N * N,
+                               NS.data_ptr(), _stream()))
+    return NS
+
+
+def s_offsets(R_host, align: int = 4):
+    """Element offsets of each graph's (R,R,R,R) block in a packed S buffer."""
+    offs, tot = [], 0
+    for r in R_host:
+        offs.append(tot)
+        tot += (int(r) ** 4 + align - 1) // align * align
+    return offs, tot
+
+
+def edge_sim(A, P, NS, R, R_host) -> tuple[torch.Tensor, torch.Tensor]:
+    _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
+    G, N, _ = A.shape
+    offs, tot = s_offsets(R_host)
+    S = torch.empty(max(tot, 4), dtype=torch.float32, device=A.device)
+    S_off = torch.tensor(offs, dtype=torch.int64, device=A.device)
+    r_max = int(max(R_host)) if len(R_host) else 1
+    _check(lib().gvae_edge_sim(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N, N * N,
+                               max(r_max, 1), S.data_ptr(), S_off.data_ptr(), _stream()))
+    return S, S_off
+
+
+def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
+               early_stop: bool = True, ws: torch.Tensor | None = None) -> torch.Tensor:
+    """X: (G, N, N) fp32, X0 in / result out (leading R x R blocks).  Returns iters_done (G,) int32."""
+    _dev(S, torch.float32), _dev(S_off, torch.int64), _dev(R, torch.int32), _dev(X, torch.float32)
+    G, N, _ = X.shape
+    need = lib().gvae_mpm_stream_ws_bytes(G, N)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=X.device)
+    done = torch.empty(G, dtype=torch.int32, device=X.device)
+    _check(lib().gvae_mpm_stream(S.data_ptr(), S_off.data_ptr(), R.data_ptr(), G, r_max,
+                                 X.data_ptr(), N, N * N, iters, tol, int(early_stop),
+                                 done.data_ptr(), ws.data_ptr(), _stream()))
+    return done
+
+
+def mpm_fused_supported(r_max: int) -> bool:
+    """Whether the single-work-group fused MPM fits its LDS budget for this size."""
+    return r_max <= MAX_NODES_LDS and 12 * r_max * r_max + 4 * r_max * ((r_max + 31) // 32) <= 159 * 1024
+
+
+def mpm_fused(A, P, NS, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
+              early_stop: bool = True) -> torch.Tensor:
+    _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
+    _dev(X, torch.float32)
+    G, N, _ = A.shape
+    done = torch.empty(G, dtype=torch.int32, device=X.device)
+    _check(lib().gvae_mpm_fused(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N, N * N,
+                                r_max, X.data_ptr(), X.shape[1], X.shape[1] * X.shape[2], iters, tol,
+                                int(early_stop), done.data_ptr(), _stream()))
+    return done
+
+
+def lsap(X, R, r_max: int, n_perm: int | None = None):
+    """Returns (perm (G, n_perm) int64, status (G,) int32)."""
+    _dev(X, torch.float32), _dev(R, torch.int32)
+    G, N, _ = X.shape
+    n_perm = N if n_perm is None else n_perm
+    perm = torch.empty(G, n_perm, dtype=torch.int64, device=X.device)
+    status = torch.empty(G, dtype=torch.int32, device=X.device)
+    _check(lib().gvae_lsap(X.data_ptr(), N, N * N, R.data_ptr(), G, r_max, perm.data_ptr(), n_perm,
+                           status.data_ptr(), _stream()))
+    return perm, status
+
+
+def x0_uniform(R_host, N: int, device) -> torch.Tensor:
+    """X0 = full((R,R), 1/R) per graph (reference model.py:317), zero elsewhere."""
+    X = torch.zeros(len(R_host), N, N, dtype=torch.float32, device=device)
+    for g, r in enumerate(R_host):
+        X[g, :r, :r] = 1.0 / r
+    return X
