@@ -1,0 +1,629 @@
+// Dense side of the GraphVAE step on gfx950: an fp32 matrix-core GEMM used for
+// every encoder/decoder contraction (forward and backward), and the small fused
+// kernels around it (GCN normalisation, per-graph BatchNorm+ReLU, pooling,
+// reparameterisation, probability matrix, losses).
+//
+// Reference semantics: graphvae/models/model.py:295-303 (encoder, heads, decoder),
+// :305-307,315 (dense logits -> probabilities), :325-361 (losses).  GCNConv follows
+// PyG 2.6.1 defaults (self loops on every feature row, D^-1/2 (A+I) D^-1/2,
+// linear without bias -> aggregate -> + bias).
+#include "gvae_dense.h"
+
+namespace gvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// GEMM: 64x64 block tile, 4 wavefronts, each wavefront one 32x32 accumulator tile
+// fed by v_mfma_f32_32x32x2_f32; K staged through LDS 16 at a time.
+// Operand lane map (32x32x2): lane l supplies A[m = l&31][k = l>>5] and
+// B[k = l>>5][n = l&31]; accumulator register r of lane l is
+// C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+// ---------------------------------------------------------------------------
+#define GT_M 64
+#define GT_N 64
+#define GT_K 16
+#define GT_LD 68
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
+  __shared__ float As[GT_K][GT_LD];
+  __shared__ float Bs[GT_K][GT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+  int z = blockIdx.z;
+  const float *A = d.A, *B = d.B;
+  float *C = d.C;
+  int k_begin = 0, k_end = d.K;
+  if (d.splits > 1) {
+    const int chunk = ((d.K + d.splits - 1) / d.splits + GT_K - 1) / GT_K * GT_K;
+    k_begin = z * chunk;
+    k_end = min(d.K, k_begin + chunk);
+    C = d.splitk_ws + (int64_t)z * d.M * d.N;
+  } else {
+    A += z * d.a_bs;
+    B += z * d.b_bs;
+    C += z * d.c_bs;
+  }
+  f32x16 acc = {0};
+  const bool a_kfast = (d.a_cs == 1), b_nfast = (d.b_cs == 1);
+  for (int k0 = k_begin; k0 < k_end; k0 += GT_K) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int m, k;
+      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * r; }
+      else { m = tid & 63; k = (tid >> 6) + 4 * r; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < d.M && gk < k_end) ? A[gm * d.a_rs + gk * d.a_cs] : 0.0f;
+      int n, kb;
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * r; }
+      else { kb = tid & 15; n = (tid >> 4) + 16 * r; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb][n] = (gn < d.N && gkb < k_end) ? B[gkb * d.b_rs + gn * d.b_cs] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GT_K; kk += 2) {
+      const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn + (lane & 31);
+  if (col >= d.N) return;
+  const bool direct = d.splits <= 1;
+  const float bv = (direct && d.bias) ? d.bias[col] : 0.0f;
+  const int64_t crs = direct ? d.c_rs : d.N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row >= d.M) continue;
+    float v = acc[r];
+    if (direct) {
+      v += bv;
+      if (d.accumulate) v += C[row * crs + col];
+      if (d.relu) v = fmaxf(v, 0.0f);
+    }
+    C[row * crs + col] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDesc d) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)d.M * d.N) return;
+  const int row = e / d.N, col = e - (int64_t)row * d.N;
+  float v = 0.0f;
+  for (int z = 0; z < d.splits; ++z) v += d.splitk_ws[(int64_t)z * d.M * d.N + e];
+  if (d.bias) v += d.bias[col];
+  if (d.accumulate) v += d.C[row * d.c_rs + col];
+  if (d.relu) v = fmaxf(v, 0.0f);
+  d.C[row * d.c_rs + col] = v;
+}
+
+int launch_gemm(const GemmDesc &d, hipStream_t s) {
+  GVAE_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, GVAE_EINVAL,
+               "gemm: bad descriptor (M=%d N=%d K=%d batch=%d)", d.M, d.N, d.K, d.batch);
+  GVAE_REQUIRE(d.splits == 1 || (d.batch == 1 && d.splitk_ws), GVAE_EINVAL,
+               "gemm: split-K needs batch == 1 and a workspace");
+  dim3 grid(ceil_div(d.N, GT_N), ceil_div(d.M, GT_M), d.splits > 1 ? d.splits : d.batch);
+  GVAE_REQUIRE(grid.y <= 65535 && grid.z <= 65535, GVAE_ELIMIT, "gemm: grid too large");
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, d);
+  if (d.splits > 1) {
+    const int64_t n = (int64_t)d.M * d.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+  }
+  return check_launch("gemm");
+}
+
+// ---------------------------------------------------------------------------
+// Ahat = D^-1/2 (A + I) D^-1/2 over the first n_x rows/cols of each graph; the
+// dense adjacency already carries a unit diagonal on the R real nodes, rows in
+// [R, n_x) are isolated feature rows with only their self loop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gcn_norm_adj_kernel(const float *__restrict__ adj,
+                                                           const int32_t *__restrict__ n_x,
+                                                           const int32_t *__restrict__ Rarr, int N,
+                                                           float *__restrict__ Ahat) {
+  __shared__ float dinv[1024];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int nx = n_x[g], R = Rarr[g];
+  const float *Ag = adj + (int64_t)g * N * N;
+  float *Og = Ahat + (int64_t)g * N * N;
+  for (int i = tid; i < N; i += 256) {
+    float deg = 1.0f;  // self loop
+    if (i < R)
+      for (int j = 0; j < R; ++j)
+        if (j != i) deg += (Ag[(int64_t)i * N + j] != 0.0f) ? 1.0f : 0.0f;
+    dinv[i] = (i < nx) ? 1.0f / sqrtf(deg) : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < N * N; e += 256) {
+    const int i = e / N, j = e - i * N;
+    float a = 0.0f;
+    if (i < nx && j < nx) {
+      if (i == j) a = 1.0f;
+      else if (i < R && j < R) a = (Ag[e] != 0.0f) ? 1.0f : 0.0f;
+    }
+    Og[e] = dinv[i] * a * dinv[j];
+  }
+}
+
+int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
+                        float *Ahat, hipStream_t s) {
+  GVAE_REQUIRE(N <= 1024, GVAE_ELIMIT, "gcn_norm_adj: N=%d > 1024", N);
+  hipLaunchKernelGGL(gcn_norm_adj_kernel, dim3(B), dim3(256), 0, s, adj, n_x, R, N, Ahat);
+  return check_launch("gcn_norm_adj");
+}
+
+// ---------------------------------------------------------------------------
+// Per-graph BatchNorm1d (eps 1e-5) + ReLU over the graph's n_x live rows.
+// One work-group per (graph, 64-column slab); 4 row lanes per column.
+// ---------------------------------------------------------------------------
+#define BN_EPS 1e-5f
+
+__device__ __forceinline__ float quad_rows_sum(float v, float (*sh)[64], int rl, int c) {
+  sh[rl][c] = v;
+  __syncthreads();
+  const float t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
+    const float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ run_mean,
+    const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
+    float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
+    float *__restrict__ var_unb_o) {
+  __shared__ float sh[4][64];
+  const int g = blockIdx.y, tid = threadIdx.x;
+  const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
+  const bool cv = c < H;
+  const int nx = n_x[g];
+  const float *Yg = Y + (int64_t)g * N * H;
+  float *Og = out + (int64_t)g * N * H;
+  const float b = cv ? bias[c] : 0.0f;
+  float mean, invstd;
+  if (train) {
+    float s = 0.0f;
+    if (cv) for (int i = rl; i < nx; i += 4) s += Yg[(int64_t)i * H + c] + b;
+    s = quad_rows_sum(s, sh, rl, cl);
+    mean = s / (float)nx;
+    float q = 0.0f;
+    if (cv) for (int i = rl; i < nx; i += 4) {
+      const float dlt = (Yg[(int64_t)i * H + c] + b) - mean;
+      q += dlt * dlt;
+    }
+    q = quad_rows_sum(q, sh, rl, cl);
+    const float var = q / (float)nx;
+    invstd = 1.0f / sqrtf(var + BN_EPS);
+    if (cv && rl == 0) {
+      mean_o[(int64_t)g * H + c] = mean;
+      invstd_o[(int64_t)g * H + c] = invstd;
+      var_unb_o[(int64_t)g * H + c] = q / (float)(nx - 1);
+    }
+  } else {
+    mean = cv ? run_mean[c] : 0.0f;
+    invstd = cv ? 1.0f / sqrtf(run_var[c] + BN_EPS) : 0.0f;
+    if (cv && rl == 0) {
+      mean_o[(int64_t)g * H + c] = mean;
+      invstd_o[(int64_t)g * H + c] = invstd;
+    }
+  }
+  if (!cv) return;
+  const float ga = gamma[c], be = beta[c];
+  for (int i = rl; i < N; i += 4) {
+    float o = 0.0f;
+    if (i < nx) {
+      const float xh = ((Yg[(int64_t)i * H + c] + b) - mean) * invstd;
+      o = fmaxf(xh * ga + be, 0.0f);
+    }
+    Og[(int64_t)i * H + c] = o;
+  }
+}
+
+int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
+                       const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
+                       int H, int train, float *out, float *mean, float *invstd, float *var_unb,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, Y, bias, gamma,
+                     beta, run_mean, run_var, n_x, N, H, train, out, mean, invstd, var_unb);
+  return check_launch("bn_relu_fwd");
+}
+
+// B sequential momentum updates, one per graph in batch order (the reference
+// applies BatchNorm graph by graph, model.py:295-296).
+__global__ void bn_running_update_kernel(const float *__restrict__ mean,
+                                         const float *__restrict__ var_unb, int B, int H,
+                                         float momentum, float *__restrict__ run_mean,
+                                         float *__restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float rm = run_mean[c], rv = run_var[c];
+  for (int g = 0; g < B; ++g) {
+    rm = momentum * mean[(int64_t)g * H + c] + (1.0f - momentum) * rm;
+    rv = momentum * var_unb[(int64_t)g * H + c] + (1.0f - momentum) * rv;
+  }
+  run_mean[c] = rm;
+  run_var[c] = rv;
+}
+
+int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
+                             float *run_mean, float *run_var, hipStream_t s) {
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, s, mean, var_unb,
+                     B, H, momentum, run_mean, run_var);
+  return check_launch("bn_running_update");
+}
+
+// backward of relu(BN(Y + bias)) in training mode:
+//   dpre = dOut * (out > 0);  dbeta = sum dpre;  dgamma = sum dpre * xhat
+//   dY = gamma * invstd * (dpre - dbeta/n - xhat * dgamma/n)   (rows >= n_x: 0)
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+    const float *__restrict__ dOut, const float *__restrict__ Y, const float *__restrict__ bias,
+    const float *__restrict__ out, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const int32_t *__restrict__ n_x, int N, int H,
+    float *__restrict__ dY, float *__restrict__ dgamma_p, float *__restrict__ dbeta_p,
+    float *__restrict__ dbias_p) {
+  __shared__ float sh[4][64];
+  const int g = blockIdx.y, tid = threadIdx.x;
+  const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
+  const bool cv = c < H;
+  const int nx = n_x[g];
+  const int64_t base = (int64_t)g * N * H;
+  const float b = cv ? bias[c] : 0.0f;
+  const float mu = cv ? mean[(int64_t)g * H + c] : 0.0f;
+  const float is = cv ? invstd[(int64_t)g * H + c] : 0.0f;
+  float sb = 0.0f, sg = 0.0f;
+  if (cv) for (int i = rl; i < nx; i += 4) {
+    const int64_t e = base + (int64_t)i * H + c;
+    const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
+    const float xh = ((Y[e] + b) - mu) * is;
+    sb += dp;
+    sg += dp * xh;
+  }
+  sb = quad_rows_sum(sb, sh, rl, cl);
+  sg = quad_rows_sum(sg, sh, rl, cl);
+  const float ga = cv ? gamma[c] : 0.0f;
+  const float inv_n = 1.0f / (float)nx;
+  float sdy = 0.0f;
+  if (cv) for (int i = rl; i < N; i += 4) {
+    const int64_t e = base + (int64_t)i * H + c;
+    float v = 0.0f;
+    if (i < nx) {
+      const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
+      const float xh = ((Y[e] + b) - mu) * is;
+      v = ga * is * (dp - sb * inv_n - xh * sg * inv_n);
+    }
+    dY[e] = v;
+    sdy += v;
+  }
+  sh[rl][cl] = sdy;
+  __syncthreads();
+  if (rl == 0 && cv) {
+    dgamma_p[(int64_t)g * H + c] = sg;
+    dbeta_p[(int64_t)g * H + c] = sb;
+    dbias_p[(int64_t)g * H + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  }
+}
+
+int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
+                       const float *gamma, const float *mean, const float *invstd,
+                       const int32_t *n_x, int B, int N, int H, float *dY, float *dgamma_p,
+                       float *dbeta_p, float *dbias_p, hipStream_t s) {
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, dOut, Y, bias,
+                     out, gamma, mean, invstd, n_x, N, H, dY, dgamma_p, dbeta_p, dbias_p);
+  return check_launch("bn_relu_bwd");
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ M, int rows, int cols,
+                                                     int64_t ld, float *__restrict__ out,
+                                                     int accumulate) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s = 0.0f;
+  if (c < cols) for (int r = rl; r < rows; r += 4) s += M[(int64_t)r * ld + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    const float t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, M, rows, cols, ld, out,
+                     accumulate);
+  return check_launch("colsum");
+}
+
+// pooled graph vector: sum over the n_x live rows divided by the real node count
+// (reference model.py:141-142,297)
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Hm,
+                                                       const int32_t *__restrict__ n_x,
+                                                       const int32_t *__restrict__ Rarr, int N, int H,
+                                                       float *__restrict__ gvec) {
+  __shared__ float sh[4][64];
+  const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const int nx = n_x[g];
+  float s = 0.0f;
+  if (c < H) for (int i = rl; i < nx; i += 4) s += Hm[((int64_t)g * N + i) * H + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < H)
+    gvec[(int64_t)g * H + c] = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) / (float)Rarr[g];
+}
+
+int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
+                    float *gvec, hipStream_t s) {
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, Hm, n_x, R, N, H,
+                     gvec);
+  return check_launch("pool_fwd");
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float *__restrict__ dgvec,
+                                                       const int32_t *__restrict__ n_x,
+                                                       const int32_t *__restrict__ Rarr, int N, int H,
+                                                       float *__restrict__ dH) {
+  const int g = blockIdx.y;
+  const int nx = n_x[g];
+  const float invR = 1.0f / (float)Rarr[g];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < N * H; e += gridDim.x * 256) {
+    const int i = e / H, c = e - i * H;
+    dH[(int64_t)g * N * H + e] = (i < nx) ? dgvec[(int64_t)g * H + c] * invR : 0.0f;
+  }
+}
+
+int launch_pool_bwd(const float *dgvec, const int32_t *n_x, const int32_t *R, int B, int N, int H,
+                    float *dH, hipStream_t s) {
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(min(ceil_div(N * H, 256), 64), B), dim3(256), 0, s, dgvec,
+                     n_x, R, N, H, dH);
+  return check_launch("pool_bwd");
+}
+
+// z = mu + eps * exp(0.5 * clamp(lvraw, -4, 4))   (reference model.py:298-299,137-139)
+__global__ void reparam_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ lvraw,
+                                   const float *__restrict__ eps, int n, float *__restrict__ z) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float lv = fminf(fmaxf(lvraw[e], -4.0f), 4.0f);
+  z[e] = mu[e] + eps[e] * expf(0.5f * lv);
+}
+
+int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, int B, int Z, float *z,
+                       hipStream_t s) {
+  const int n = B * Z;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, mu, lvraw, eps, n,
+                     z);
+  return check_launch("reparam_fwd");
+}
+
+// dmu = dz + ck * mu / Z ;  dlv = dz * eps * 0.5 * exp(0.5 lv) - ck * 0.5 * (1 - exp(lv)) / Z,
+// zero where lvraw was clamped;  ck = c_kl * d_up[1] / B  (KL term, model.py:361,369)
+__global__ void reparam_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ mu,
+                                   const float *__restrict__ lvraw, const float *__restrict__ eps,
+                                   int n, int Z, float ck, const float *__restrict__ d_up,
+                                   float *__restrict__ dmu, float *__restrict__ dlvraw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (d_up) ck *= d_up[1];
+  const float raw = lvraw[e];
+  const float lv = fminf(fmaxf(raw, -4.0f), 4.0f);
+  const float g = dz[e];
+  dmu[e] = g + ck * mu[e] / (float)Z;
+  const float dlv = g * eps[e] * 0.5f * expf(0.5f * lv) - ck * 0.5f * (1.0f - expf(lv)) / (float)Z;
+  dlvraw[e] = (raw >= -4.0f && raw <= 4.0f) ? dlv : 0.0f;
+}
+
+int launch_reparam_bwd(const float *dz, const float *mu, const float *lvraw, const float *eps, int B,
+                       int Z, float c_kl, const float *d_up, float *dmu, float *dlvraw,
+                       hipStream_t s) {
+  const int n = B * Z;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dz, mu, lvraw, eps,
+                     n, Z, c_kl / (float)B, d_up, dmu, dlvraw);
+  return check_launch("reparam_bwd");
+}
+
+__global__ void relu_mask_kernel(float *__restrict__ dX, const float *__restrict__ act, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && !(act[e] > 0.0f)) dX[e] = 0.0f;
+}
+
+int launch_relu_mask(float *dX, const float *act, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dX, act, n);
+  return check_launch("relu_mask");
+}
+
+// index of pair (a,b), a < b, in row-major upper-triangle order (torch.triu_indices(N,N,1))
+__device__ __forceinline__ int tri_index(int a, int b, int N) {
+  return a * N - (a * (a + 1)) / 2 + (b - a - 1);
+}
+
+// P = sigmoid(dense logits): off-diagonal from the edge head (symmetric), diagonal
+// from the node head (reference model.py:305-307,315)
+__global__ void prob_kernel(const float *__restrict__ vec, const float *__restrict__ node, int N,
+                            int U, float *__restrict__ P) {
+  const int g = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+    const int a = e / N, b = e - a * N;
+    const float x = (a == b) ? node[(int64_t)g * N + a]
+                             : vec[(int64_t)g * U + (a < b ? tri_index(a, b, N) : tri_index(b, a, N))];
+    P[(int64_t)g * N * N + e] = 1.0f / (1.0f + expf(-x));
+  }
+}
+
+int launch_prob(const float *vec, const float *node, int B, int N, float *P, hipStream_t s) {
+  const int U = N * (N - 1) / 2;
+  hipLaunchKernelGGL(prob_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, vec, node,
+                     N, U, P);
+  return check_launch("prob");
+}
+
+// ---------------------------------------------------------------------------
+// Losses, one work-group per graph (reference model.py:325-361):
+//   edge BCE-with-logits (pos_weight) over the R(R-1)/2 permuted pairs, mean
+//   node BCE-with-logits over N entries, targets 1 for k < R, weight clamp((N-R)/(R+1e-8),1,5)
+//   KL = -0.5 * mean_Z(1 + lv - mu^2 - exp(lv))
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bce_logits(float x, float y, float pw) {
+  const float lw = 1.0f + (pw - 1.0f) * y;
+  return (1.0f - y) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f));
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ float block_max_256(float v, float *sh) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(
+    const float *__restrict__ vec, const float *__restrict__ node, const float *__restrict__ adj,
+    const float *__restrict__ mu, const float *__restrict__ lvraw, const int64_t *__restrict__ perm,
+    const int32_t *__restrict__ Rarr, int N, int Z, const float *__restrict__ pos_weight,
+    float *__restrict__ rec_i, float *__restrict__ kl_i, float *__restrict__ maxlogit_i) {
+  __shared__ float sh[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int R = Rarr[g], U = N * (N - 1) / 2;
+  const float pw = pos_weight[0];
+  const float *vg = vec + (int64_t)g * U, *ng = node + (int64_t)g * N;
+  const float *Ag = adj + (int64_t)g * N * N;
+  const int64_t *pg = perm + (int64_t)g * N;
+  // edge term: pair t = (r,c), r < c < R in row-major order
+  const int npairs = R * (R - 1) / 2;
+  float s = 0.0f;
+  for (int t = tid; t < npairs; t += 256) {
+    // invert t -> (r,c): r is the largest row with start(r) <= t, start(r) = r*R - r(r+1)/2
+    int r = (int)((2.0f * R - 1.0f - sqrtf((2.0f * R - 1.0f) * (2.0f * R - 1.0f) - 8.0f * t)) * 0.5f);
+    while (r > 0 && r * R - (r * (r + 1)) / 2 > t) --r;
+    while ((r + 1) * R - ((r + 1) * (r + 2)) / 2 <= t) ++r;
+    const int c = t - (r * R - (r * (r + 1)) / 2) + r + 1;
+    const int pr = (int)pg[r], pc = (int)pg[c];
+    const float x = vg[pr < pc ? tri_index(pr, pc, N) : tri_index(pc, pr, N)];
+    const float y = Ag[(int64_t)pr * N + pc];
+    s += bce_logits(x, y, pw);
+  }
+  const float edge = block_sum_256(s, sh) / (float)npairs;
+  // node term
+  const float pwn = fminf(fmaxf((float)(N - R) / ((float)R + 1e-8f), 1.0f), 5.0f);
+  s = 0.0f;
+  for (int k = tid; k < N; k += 256) s += bce_logits(ng[k], k < R ? 1.0f : 0.0f, pwn);
+  const float nodel = block_sum_256(s, sh) / (float)N;
+  // KL
+  s = 0.0f;
+  for (int k = tid; k < Z; k += 256) {
+    const float m = mu[(int64_t)g * Z + k];
+    const float lv = fminf(fmaxf(lvraw[(int64_t)g * Z + k], -4.0f), 4.0f);
+    s += 1.0f + lv - m * m - expf(lv);
+  }
+  const float kl = -0.5f * (block_sum_256(s, sh) / (float)Z);
+  // diagnostics: max |logit| over the edge head and the node head with padded
+  // entries read as -10 (model.py:347-356)
+  float mx = 0.0f;
+  for (int t = tid; t < U; t += 256) mx = fmaxf(mx, fabsf(vg[t]));
+  for (int k = tid; k < N; k += 256) mx = fmaxf(mx, k < R ? fabsf(ng[k]) : 10.0f);
+  mx = block_max_256(mx, sh);
+  if (tid == 0) {
+    rec_i[g] = edge + nodel;
+    kl_i[g] = kl;
+    maxlogit_i[g] = mx;
+  }
+}
+
+// out4 = [mean rec_i, mean kl_i, max maxlogit_i, max_k clamp(lvraw[B-1,k])]
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ rec_i,
+                                                          const float *__restrict__ kl_i,
+                                                          const float *__restrict__ maxlogit_i,
+                                                          const float *__restrict__ lvraw, int B,
+                                                          int Z, float *__restrict__ out4) {
+  __shared__ float sh[4];
+  const int tid = threadIdx.x;
+  float a = 0.0f, b = 0.0f, m = -INFINITY, l = -INFINITY;
+  for (int g = tid; g < B; g += 256) {
+    a += rec_i[g];
+    b += kl_i[g];
+    m = fmaxf(m, maxlogit_i[g]);
+  }
+  for (int k = tid; k < Z; k += 256)
+    l = fmaxf(l, fminf(fmaxf(lvraw[(int64_t)(B - 1) * Z + k], -4.0f), 4.0f));
+  a = block_sum_256(a, sh);
+  b = block_sum_256(b, sh);
+  m = block_max_256(m, sh);
+  l = block_max_256(l, sh);
+  if (tid == 0) {
+    out4[0] = a / (float)B;
+    out4[1] = b / (float)B;
+    out4[2] = m;
+    out4[3] = l;
+  }
+}
+
+int launch_loss_fwd(const float *vec, const float *node, const float *adj, const float *mu,
+                    const float *lvraw, const int64_t *perm, const int32_t *R, int B, int N, int Z,
+                    const float *pos_weight, float *rec_i, float *kl_i, float *maxlogit_i,
+                    float *out4, hipStream_t s) {
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, s, vec, node, adj, mu, lvraw, perm, R, N,
+                     Z, pos_weight, rec_i, kl_i, maxlogit_i);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, rec_i, kl_i, maxlogit_i, lvraw, B,
+                     Z, out4);
+  return check_launch("loss_fwd");
+}
+
+// d(rec)/d(logits).  rec = mean_g (edge_g + node_g); the edge mean runs over all
+// unordered pairs of real nodes, each exactly once whatever the permutation, so
+//   dvec[g,(a,b)] = cr/npairs * ((1-y) - lw*(1-sigmoid(x)))   for a < b < R, else 0
+// with cr = c_rec * d_up[0] / B.
+__global__ void loss_bwd_kernel(const float *__restrict__ vec, const float *__restrict__ node,
+                                const float *__restrict__ adj, const int32_t *__restrict__ Rarr,
+                                int N, const float *__restrict__ pos_weight, float cr,
+                                const float *__restrict__ d_up, float *__restrict__ dvec,
+                                float *__restrict__ dnode) {
+  const int g = blockIdx.y;
+  const int R = Rarr[g], U = N * (N - 1) / 2;
+  if (d_up) cr *= d_up[0];
+  const float pw = pos_weight[0];
+  const float inv_pairs = 1.0f / (float)(R * (R - 1) / 2);
+  const float *Ag = adj + (int64_t)g * N * N;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+    const int a = e / N, b = e - a * N;
+    if (a < b) {
+      const int t = tri_index(a, b, N);
+      float gr = 0.0f;
+      if (b < R) {
+        const float x = vec[(int64_t)g * U + t], y = Ag[e];
+        const float lw = 1.0f + (pw - 1.0f) * y;
+        const float sg = 1.0f / (1.0f + expf(-x));
+        gr = cr * inv_pairs * ((1.0f - y) - lw * (1.0f - sg));
+      }
+      dvec[(int64_t)g * U + t] = gr;
+    } else if (a == b) {
+      const float pwn = fminf(fmaxf((float)(N - R) / ((float)R + 1e-8f), 1.0f), 5.0f);
+      const float x = node[(int64_t)g * N + a], y = a < R ? 1.0f : 0.0f;
+      const float lw = 1.0f + (pwn - 1.0f) * y;
+      const float sg = 1.0f / (1.0f + expf(-x));
+      dnode[(int64_t)g * N + a] = cr / (float)N * ((1.0f - y) - lw * (1.0f - sg));
+    }
+  }
+}
+
+int launch_loss_bwd(const float *vec, const float *node, const float *adj, const int32_t *R, int B,
+                    int N, const float *pos_weight, float c_rec, const float *d_up, float *dvec,
+                    float *dnode, hipStream_t s) {
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, vec,
+                     node, adj, R, N, pos_weight, c_rec / (float)B, d_up, dvec, dnode);
+  return check_launch("loss_bwd");
+}
+
+}  // namespace gvae

@@ -20,7 +20,9 @@
 //                 floor(n/8) groups of 8 lanes, each lane ilp4-summed over the group
 //                 index; result = 0 + tail elements in order + lane 0 + ... + lane 7.
 //   norm          8 lane accumulators, acc[l] = fma(x, x, acc[l]) over consecutive
-//                 groups of 8; lanes folded 0+1+...+7; tail elements fused in; sqrt.
+//                 groups of 8; lanes folded 0+1+...+7; then the n % 8 tail elements:
+//                 if there are 4 or more, the first four squares are rounded separately
+//                 and added one by one, all other tail elements are fused in; sqrt.
 #pragma once
 #include <hip/hip_runtime.h>
 

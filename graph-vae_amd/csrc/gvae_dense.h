@@ -1,0 +1,66 @@
+// Internal launch helpers of the dense (encoder / decoder / loss / optimiser)
+// kernels, shared between dense.hip and step.hip.
+#pragma once
+#include "gvae_common.h"
+
+namespace gvae {
+
+// C[b] (M x N, row stride c_rs, unit column stride)
+//   = op(A[b]) (M x K, element (m,k) at A + m*a_rs + k*a_cs)
+//   * op(B[b]) (K x N, element (k,n) at B + k*b_rs + n*b_cs)   [+ bias[n]] [relu] [+= C]
+// fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32), which is a
+// k-ordered fp32 fma chain, i.e. plain fp32 numerics.
+struct GemmDesc {
+  const float *A = nullptr, *B = nullptr, *bias = nullptr;
+  float *C = nullptr;
+  int M = 0, N = 0, K = 0;
+  int64_t a_rs = 0, a_cs = 0, b_rs = 0, b_cs = 0, c_rs = 0;
+  int batch = 1;
+  int64_t a_bs = 0, b_bs = 0, c_bs = 0;
+  int relu = 0, accumulate = 0;
+  // split-K (batch == 1 only): partial products go to `splitk_ws`
+  // (splits * M * N floats) and are then summed in split order.
+  int splits = 1;
+  float *splitk_ws = nullptr;
+};
+int launch_gemm(const GemmDesc &d, hipStream_t s);
+
+int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
+                        float *Ahat, hipStream_t s);
+// BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics
+// (written to mean / invstd / var_unbiased, each (B,H)); else running statistics.
+int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
+                       const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
+                       int H, int train, float *out, float *mean, float *invstd, float *var_unb,
+                       hipStream_t s);
+int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
+                             float *run_mean, float *run_var, hipStream_t s);
+// dY (B,N,H) from dOut; per-graph partial sums dgamma_p, dbeta_p, dbias_p (B,H)
+int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
+                       const float *gamma, const float *mean, const float *invstd,
+                       const int32_t *n_x, int B, int N, int H, float *dY, float *dgamma_p,
+                       float *dbeta_p, float *dbias_p, hipStream_t s);
+// out[c] (+)= sum_r M[r*ld + c]   (rows summed in index order)
+int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
+                  hipStream_t s);
+int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
+                    float *gvec, hipStream_t s);
+int launch_pool_bwd(const float *dgvec, const int32_t *n_x, const int32_t *R, int B, int N, int H,
+                    float *dH, hipStream_t s);
+int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, int B, int Z, float *z,
+                       hipStream_t s);
+// dmu, dlvraw from dz and the KL term (coefficient c_kl / B per graph)
+int launch_reparam_bwd(const float *dz, const float *mu, const float *lvraw, const float *eps, int B,
+                       int Z, float c_kl, const float *d_up, float *dmu, float *dlvraw,
+                       hipStream_t s);
+int launch_relu_mask(float *dX, const float *act, int64_t n, hipStream_t s);
+int launch_prob(const float *vec, const float *node, int B, int N, float *P, hipStream_t s);
+int launch_loss_fwd(const float *vec, const float *node, const float *adj, const float *mu,
+                    const float *lvraw, const int64_t *perm, const int32_t *R, int B, int N, int Z,
+                    const float *pos_weight, float *rec_i, float *kl_i, float *maxlogit_i,
+                    float *out4, hipStream_t s);
+int launch_loss_bwd(const float *vec, const float *node, const float *adj, const int32_t *R, int B,
+                    int N, const float *pos_weight, float c_rec, const float *d_up, float *dvec,
+                    float *dnode, hipStream_t s);
+
+}  // namespace gvae

@@ -283,7 +283,10 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
   float s = __shfl(acc, 0, 64);
 #pragma unroll
   for (int l = 1; l < 8; ++l) s = s + __shfl(acc, l, 64);
-  for (int k = 0; k < ntail; ++k) s = __fmaf_rn(tail[k], tail[k], s);
+  int k = 0;
+  if (ntail >= 4)
+    for (; k < 4; ++k) s = s + __fmul_rn(tail[k], tail[k]);  // rounded squares, not fused
+  for (; k < ntail; ++k) s = __fmaf_rn(tail[k], tail[k], s);
   return sqrtf(s);
 }
 

@@ -1,0 +1,403 @@
+// Orchestration of one GraphVAE training step on a batch of padded dense graphs:
+// forward (encoder -> heads -> decoder -> matching -> assignment -> losses),
+// backward (all parameter gradients into one flat buffer) and the fused
+// clip + Adam update.  Every buffer comes from the caller; nothing is allocated.
+//
+// Reference: graphvae/models/model.py:281-373 (forward), graphvae/train/train_ddp.py:282-316
+// (loss weighting, clipping, Adam).
+#include "gvae_dense.h"
+
+namespace gvae {
+
+static inline int64_t align4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+static int64_t param_layout(const gvae_dims *d, int64_t *off, int64_t *size) {
+  const int64_t F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
+  const int64_t sz[GVAE_P_COUNT] = {
+      H, H * F, H, H,          // conv1.bias, conv1.lin.weight, bn1.weight, bn1.bias
+      H, H * H, H, H,          // conv2.bias, conv2.lin.weight, bn2.weight, bn2.bias
+      Z * H, Z, Z * H, Z,      // mu.weight, mu.bias, logvar.weight, logvar.bias
+      H * Z, H, U * H, U,      // dec_edge.0.weight/.bias, dec_edge.2.weight/.bias
+      H * Z, H, N * H, N};     // dec_node.0.weight/.bias, dec_node.2.weight/.bias
+  int64_t tot = 0;
+  for (int i = 0; i < GVAE_P_COUNT; ++i) {
+    if (off) off[i] = tot;
+    if (size) size[i] = sz[i];
+    tot += align4(sz[i]);
+  }
+  return tot;
+}
+
+struct Workspace {
+  float *Ahat, *H0a, *Y1, *H1, *H0b, *Y2, *H2;
+  float *mean1, *invstd1, *varu1, *mean2, *invstd2, *varu2;
+  float *gvec, *mu, *lvraw, *z, *he, *hn, *vec, *node;
+  float *P, *NS, *X;
+  float *rec_i, *kl_i, *maxlogit_i;
+  // backward
+  float *dvec, *dnode, *dhe, *dhn, *dz, *dmu, *dlv, *dgvec, *dAct, *dY, *dH0;
+  float *dgam_p, *dbet_p, *dbias_p;
+  float *splitk;
+  int32_t *status;
+  char *mpm_ws;
+  int64_t bytes;
+};
+
+static const int kMaxSplits = 64;
+
+static Workspace carve(const gvae_dims *d, int B, char *base) {
+  const int64_t F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
+  (void)F;
+  Workspace w{};
+  int64_t off = 0;
+  auto take = [&](int64_t nfloat) {
+    float *p = reinterpret_cast<float *>(base + off);
+    off += (nfloat * 4 + 255) & ~(int64_t)255;
+    return p;
+  };
+  const int64_t BNH = (int64_t)B * N * H, BNN = (int64_t)B * N * N, BH = (int64_t)B * H;
+  w.Ahat = take(BNN); w.H0a = take(BNH); w.Y1 = take(BNH); w.H1 = take(BNH);
+  w.H0b = take(BNH); w.Y2 = take(BNH); w.H2 = take(BNH);
+  w.mean1 = take(BH); w.invstd1 = take(BH); w.varu1 = take(BH);
+  w.mean2 = take(BH); w.invstd2 = take(BH); w.varu2 = take(BH);
+  w.gvec = take(BH); w.mu = take((int64_t)B * Z); w.lvraw = take((int64_t)B * Z);
+  w.z = take((int64_t)B * Z); w.he = take(BH); w.hn = take(BH);
+  w.vec = take((int64_t)B * U); w.node = take((int64_t)B * N);
+  w.P = take(BNN); w.NS = take(BNN); w.X = take(BNN);
+  w.rec_i = take(B); w.kl_i = take(B); w.maxlogit_i = take(B);
+  w.dvec = take((int64_t)B * U); w.dnode = take((int64_t)B * N);
+  w.dhe = take(BH); w.dhn = take(BH); w.dz = take((int64_t)B * Z);
+  w.dmu = take((int64_t)B * Z); w.dlv = take((int64_t)B * Z); w.dgvec = take(BH);
+  w.dAct = take(BNH); w.dY = take(BNH); w.dH0 = take(BNH);
+  w.dgam_p = take(BH); w.dbet_p = take(BH); w.dbias_p = take(BH);
+  int64_t sk = (int64_t)kMaxSplits * H * (H > F ? H : F);
+  const int64_t sk2 = (int64_t)kMaxSplits * B * H;
+  if (sk2 > sk) sk = sk2;
+  w.splitk = take(sk);
+  w.status = reinterpret_cast<int32_t *>(take(B));
+  w.mpm_ws = reinterpret_cast<char *>(take((gvae_mpm_stream_ws_bytes(B, (int)N) + 3) / 4));
+  w.bytes = off;
+  return w;
+}
+
+struct Params {
+  const float *p[GVAE_P_COUNT];
+};
+static Params bind(const gvae_dims *d, const float *flat) {
+  int64_t off[GVAE_P_COUNT];
+  param_layout(d, off, nullptr);
+  Params P;
+  for (int i = 0; i < GVAE_P_COUNT; ++i) P.p[i] = flat + off[i];
+  return P;
+}
+
+static int pick_splits(int M, int N, int K) {
+  const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
+  if (tiles >= 128 || K < 1024) return 1;
+  int s = K / 512;
+  if (s * tiles > 1024) s = 1024 / tiles;
+  if (s > kMaxSplits) s = kMaxSplits;
+  return s < 1 ? 1 : s;
+}
+
+// C (M x N) = A (M x K, row-major lda) * W^T, W (N x K) row-major  [+bias][relu]
+static int linear_fwd(const float *A, int64_t lda, const float *W, const float *bias, float *C, int M,
+                      int N, int K, int relu, hipStream_t s) {
+  GemmDesc g;
+  g.A = A; g.a_rs = lda; g.a_cs = 1;
+  g.B = W; g.b_rs = 1; g.b_cs = K;
+  g.C = C; g.c_rs = N; g.bias = bias; g.M = M; g.N = N; g.K = K; g.relu = relu;
+  return launch_gemm(g, s);
+}
+// dA (M x K) (+)= dC (M x N) * W, W (N x K) row-major
+static int linear_bwd_input(const float *dC, const float *W, float *dA, int M, int N, int K,
+                            int accumulate, float *splitk, hipStream_t s) {
+  GemmDesc g;
+  g.A = dC; g.a_rs = N; g.a_cs = 1;
+  g.B = W; g.b_rs = K; g.b_cs = 1;
+  g.C = dA; g.c_rs = K; g.M = M; g.N = K; g.K = N; g.accumulate = accumulate;
+  g.splits = pick_splits(M, K, N);
+  g.splitk_ws = splitk;
+  return launch_gemm(g, s);
+}
+// dW (N x K) = dC^T (N x M) * A (M x K)
+static int linear_bwd_weight(const float *dC, const float *A, int64_t lda, float *dW, int M, int N,
+                             int K, float *splitk, hipStream_t s) {
+  GemmDesc g;
+  g.A = dC; g.a_rs = 1; g.a_cs = N;
+  g.B = A; g.b_rs = lda; g.b_cs = 1;
+  g.C = dW; g.c_rs = K; g.M = N; g.N = K; g.K = M;
+  g.splits = pick_splits(N, K, M);
+  g.splitk_ws = splitk;
+  return launch_gemm(g, s);
+}
+// Y[b] (N x H) = Ahat[b] (N x N) * X[b] (N x H)
+static int aggregate(const float *Ahat, const float *X, float *Y, int B, int N, int H, hipStream_t s) {
+  GemmDesc g;
+  g.A = Ahat; g.a_rs = N; g.a_cs = 1; g.a_bs = (int64_t)N * N;
+  g.B = X; g.b_rs = H; g.b_cs = 1; g.b_bs = (int64_t)N * H;
+  g.C = Y; g.c_rs = H; g.c_bs = (int64_t)N * H;
+  g.M = N; g.N = H; g.K = N; g.batch = B;
+  return launch_gemm(g, s);
+}
+
+__global__ void x0_init_kernel(const int32_t *__restrict__ Rarr, int N, float *__restrict__ X) {
+  const int g = blockIdx.y;
+  const int R = Rarr[g];
+  const float v = R > 0 ? (float)(1.0 / (double)R) : 0.0f;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+    const int i = e / N, a = e - i * N;
+    X[(int64_t)g * N * N + e] = (i < R && a < R) ? v : 0.0f;
+  }
+}
+
+__global__ void identity_perm_kernel(int64_t *perm, int B, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B * N) perm[e] = e % N;
+}
+
+// ---- optimiser -------------------------------------------------------------------
+#define NORM_BLOCKS 256
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float *__restrict__ g, int64_t n,
+                                                          float scale, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)NORM_BLOCKS * 256) {
+    const double v = (double)(g[e] * scale);
+    s += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// clip by global norm (torch.nn.utils.clip_grad_norm_: coef = min(1, max/(norm+1e-6))),
+// then Adam with L2 weight decay (torch.optim.Adam defaults, amsgrad off)
+__global__ __launch_bounds__(256) void adam_clip_kernel(
+    float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+    int64_t n, float grad_scale, float clip_max, const double *__restrict__ partial, float step_size,
+    float bc2_sqrt, float b1, float b2, float eps, float wd, float *__restrict__ norm_out) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < NORM_BLOCKS; ++k) t += partial[k];
+    const float nrm = (float)sqrt(t);
+    float coef = 1.0f;
+    if (clip_max > 0.0f) coef = fminf(clip_max / (nrm + 1e-6f), 1.0f);
+    s_coef = coef;
+    if (norm_out && blockIdx.x == 0) norm_out[0] = nrm;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    float gr = g[e] * grad_scale * coef;
+    const float w = p[e];
+    gr = gr + wd * w;
+    const float mm = b1 * m[e] + (1.0f - b1) * gr;
+    const float vv = b2 * v[e] + (1.0f - b2) * gr * gr;
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] = w - step_size * (mm / denom);
+  }
+}
+
+}  // namespace gvae
+
+using namespace gvae;
+
+extern "C" {
+
+int64_t gvae_param_layout(const gvae_dims *d, int64_t *offsets, int64_t *sizes) {
+  if (!d || d->F <= 0 || d->H <= 0 || d->Z <= 0 || d->N < 2) return -1;
+  return param_layout(d, offsets, sizes);
+}
+
+int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs) {
+  if (!d || n_graphs <= 0) return 0;
+  return carve(d, n_graphs, nullptr).bytes;
+}
+
+#define TRY(x)            \
+  do {                    \
+    int rc_ = (x);        \
+    if (rc_) return rc_;  \
+  } while (0)
+
+int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
+                      const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
+                      int r_max, const float *d_eps, const float *d_pos_weight, int train,
+                      int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                      const int64_t *d_S_off, void *d_ws, float *d_out4, int64_t *d_perm,
+                      int32_t *d_iters_done, void *stream) {
+  GVAE_REQUIRE(d && d_params && d_bn_state && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight &&
+                   d_ws && d_out4 && d_perm && d_iters_done,
+               GVAE_EINVAL, "step_forward: null pointer");
+  GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535 && r_max > 0 && r_max <= d->N, GVAE_EINVAL,
+               "step_forward: bad sizes (n_graphs=%d r_max=%d N=%d)", n_graphs, r_max, d->N);
+  GVAE_REQUIRE(matching >= GVAE_MATCH_NONE && matching <= GVAE_MATCH_FUSED, GVAE_EINVAL,
+               "step_forward: unknown matching mode %d", matching);
+  GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
+               "step_forward: streaming matching needs the S buffer and its offsets");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
+  const Workspace w = carve(d, B, (char *)d_ws);
+  const Params P = bind(d, d_params);
+  float *rm1 = d_bn_state, *rv1 = rm1 + H, *rm2 = rv1 + H, *rv2 = rm2 + H;
+
+  // encoder (model.py:295-297)
+  TRY(launch_gcn_norm_adj(d_adj, d_n_x, d_R, B, N, w.Ahat, s));
+  TRY(linear_fwd(d_x, F, P.p[GVAE_P_CONV1_W], nullptr, w.H0a, B * N, H, F, 0, s));
+  TRY(aggregate(w.Ahat, w.H0a, w.Y1, B, N, H, s));
+  TRY(launch_bn_relu_fwd(w.Y1, P.p[GVAE_P_CONV1_B], P.p[GVAE_P_BN1_W], P.p[GVAE_P_BN1_B], rm1, rv1,
+                         d_n_x, B, N, H, train, w.H1, w.mean1, w.invstd1, w.varu1, s));
+  TRY(linear_fwd(w.H1, H, P.p[GVAE_P_CONV2_W], nullptr, w.H0b, B * N, H, H, 0, s));
+  TRY(aggregate(w.Ahat, w.H0b, w.Y2, B, N, H, s));
+  TRY(launch_bn_relu_fwd(w.Y2, P.p[GVAE_P_CONV2_B], P.p[GVAE_P_BN2_W], P.p[GVAE_P_BN2_B], rm2, rv2,
+                         d_n_x, B, N, H, train, w.H2, w.mean2, w.invstd2, w.varu2, s));
+  if (train) {
+    TRY(launch_bn_running_update(w.mean1, w.varu1, B, H, 0.1f, rm1, rv1, s));
+    TRY(launch_bn_running_update(w.mean2, w.varu2, B, H, 0.1f, rm2, rv2, s));
+  }
+  TRY(launch_pool_fwd(w.H2, d_n_x, d_R, B, N, H, w.gvec, s));
+  // heads + reparameterisation (model.py:298-299)
+  TRY(linear_fwd(w.gvec, H, P.p[GVAE_P_MU_W], P.p[GVAE_P_MU_B], w.mu, B, Z, H, 0, s));
+  TRY(linear_fwd(w.gvec, H, P.p[GVAE_P_LV_W], P.p[GVAE_P_LV_B], w.lvraw, B, Z, H, 0, s));
+  TRY(launch_reparam_fwd(w.mu, w.lvraw, d_eps, B, Z, w.z, s));
+  // decoder (model.py:302-303)
+  TRY(linear_fwd(w.z, Z, P.p[GVAE_P_DE1_W], P.p[GVAE_P_DE1_B], w.he, B, H, Z, 1, s));
+  TRY(linear_fwd(w.he, H, P.p[GVAE_P_DE2_W], P.p[GVAE_P_DE2_B], w.vec, B, U, H, 0, s));
+  TRY(linear_fwd(w.z, Z, P.p[GVAE_P_DN1_W], P.p[GVAE_P_DN1_B], w.hn, B, H, Z, 1, s));
+  TRY(linear_fwd(w.hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], w.node, B, N, H, 0, s));
+  // matching (model.py:312-323)
+  if (matching == GVAE_MATCH_NONE) {
+    hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
+    TRY(hipMemsetAsync(d_iters_done, 0, sizeof(int32_t) * B, s) == hipSuccess ? 0 : GVAE_ELAUNCH);
+  } else {
+    TRY(launch_prob(w.vec, w.node, B, N, w.P, s));
+    TRY(gvae_node_sim(d_adj, w.P, d_R, B, N, (int64_t)N * N, w.NS, s));
+    hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
+                       w.X);
+    if (matching == GVAE_MATCH_STREAM) {
+      TRY(gvae_edge_sim(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, d_S, d_S_off, s));
+      TRY(gvae_mpm_stream(d_S, d_S_off, d_R, B, r_max, w.X, N, (int64_t)N * N, mpm_iters, tol,
+                          early_stop, d_iters_done, w.mpm_ws, s));
+    } else {
+      TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
+                         mpm_iters, tol, early_stop, d_iters_done, s));
+    }
+    TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
+  }
+  // losses (model.py:325-373)
+  TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,
+                      w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
+  return check_launch("step_forward");
+}
+
+int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d_x,
+                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
+                       const float *d_eps, const float *d_pos_weight, float c_rec, float c_kl,
+                       const float *d_up, void *d_ws, float *d_grads, void *stream) {
+  GVAE_REQUIRE(d && d_params && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight && d_ws &&
+                   d_grads,
+               GVAE_EINVAL, "step_backward: null pointer");
+  GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535, GVAE_EINVAL, "step_backward: bad n_graphs=%d",
+               n_graphs);
+  hipStream_t s = (hipStream_t)stream;
+  const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
+  const Workspace w = carve(d, B, (char *)d_ws);
+  const Params P = bind(d, d_params);
+  int64_t off[GVAE_P_COUNT];
+  param_layout(d, off, nullptr);
+  auto G = [&](int i) { return d_grads + off[i]; };
+
+  TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight, c_rec, d_up, w.dvec, w.dnode, s));
+  // edge head
+  TRY(linear_bwd_weight(w.dvec, w.he, H, G(GVAE_P_DE2_W), B, U, H, w.splitk, s));
+  TRY(launch_colsum(w.dvec, B, U, U, G(GVAE_P_DE2_B), 0, s));
+  TRY(linear_bwd_input(w.dvec, P.p[GVAE_P_DE2_W], w.dhe, B, U, H, 0, w.splitk, s));
+  TRY(launch_relu_mask(w.dhe, w.he, (int64_t)B * H, s));
+  TRY(linear_bwd_weight(w.dhe, w.z, Z, G(GVAE_P_DE1_W), B, H, Z, w.splitk, s));
+  TRY(launch_colsum(w.dhe, B, H, H, G(GVAE_P_DE1_B), 0, s));
+  TRY(linear_bwd_input(w.dhe, P.p[GVAE_P_DE1_W], w.dz, B, H, Z, 0, w.splitk, s));
+  // node head
+  TRY(linear_bwd_weight(w.dnode, w.hn, H, G(GVAE_P_DN2_W), B, N, H, w.splitk, s));
+  TRY(launch_colsum(w.dnode, B, N, N, G(GVAE_P_DN2_B), 0, s));
+  TRY(linear_bwd_input(w.dnode, P.p[GVAE_P_DN2_W], w.dhn, B, N, H, 0, w.splitk, s));
+  TRY(launch_relu_mask(w.dhn, w.hn, (int64_t)B * H, s));
+  TRY(linear_bwd_weight(w.dhn, w.z, Z, G(GVAE_P_DN1_W), B, H, Z, w.splitk, s));
+  TRY(launch_colsum(w.dhn, B, H, H, G(GVAE_P_DN1_B), 0, s));
+  TRY(linear_bwd_input(w.dhn, P.p[GVAE_P_DN1_W], w.dz, B, H, Z, 1, w.splitk, s));
+  // reparameterisation + KL
+  TRY(launch_reparam_bwd(w.dz, w.mu, w.lvraw, d_eps, B, Z, c_kl, d_up, w.dmu, w.dlv, s));
+  TRY(linear_bwd_weight(w.dmu, w.gvec, H, G(GVAE_P_MU_W), B, Z, H, w.splitk, s));
+  TRY(launch_colsum(w.dmu, B, Z, Z, G(GVAE_P_MU_B), 0, s));
+  TRY(linear_bwd_weight(w.dlv, w.gvec, H, G(GVAE_P_LV_W), B, Z, H, w.splitk, s));
+  TRY(launch_colsum(w.dlv, B, Z, Z, G(GVAE_P_LV_B), 0, s));
+  TRY(linear_bwd_input(w.dmu, P.p[GVAE_P_MU_W], w.dgvec, B, Z, H, 0, w.splitk, s));
+  TRY(linear_bwd_input(w.dlv, P.p[GVAE_P_LV_W], w.dgvec, B, Z, H, 1, w.splitk, s));
+  // encoder layer 2
+  TRY(launch_pool_bwd(w.dgvec, d_n_x, d_R, B, N, H, w.dAct, s));
+  TRY(launch_bn_relu_bwd(w.dAct, w.Y2, P.p[GVAE_P_CONV2_B], w.H2, P.p[GVAE_P_BN2_W], w.mean2,
+                         w.invstd2, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
+  TRY(launch_colsum(w.dgam_p, B, H, H, G(GVAE_P_BN2_W), 0, s));
+  TRY(launch_colsum(w.dbet_p, B, H, H, G(GVAE_P_BN2_B), 0, s));
+  TRY(launch_colsum(w.dbias_p, B, H, H, G(GVAE_P_CONV2_B), 0, s));
+  TRY(aggregate(w.Ahat, w.dY, w.dH0, B, N, H, s));  // Ahat is symmetric
+  TRY(linear_bwd_weight(w.dH0, w.H1, H, G(GVAE_P_CONV2_W), B * N, H, H, w.splitk, s));
+  TRY(linear_bwd_input(w.dH0, P.p[GVAE_P_CONV2_W], w.dAct, B * N, H, H, 0, w.splitk, s));
+  // encoder layer 1
+  TRY(launch_bn_relu_bwd(w.dAct, w.Y1, P.p[GVAE_P_CONV1_B], w.H1, P.p[GVAE_P_BN1_W], w.mean1,
+                         w.invstd1, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
+  TRY(launch_colsum(w.dgam_p, B, H, H, G(GVAE_P_BN1_W), 0, s));
+  TRY(launch_colsum(w.dbet_p, B, H, H, G(GVAE_P_BN1_B), 0, s));
+  TRY(launch_colsum(w.dbias_p, B, H, H, G(GVAE_P_CONV1_B), 0, s));
+  TRY(aggregate(w.Ahat, w.dY, w.dH0, B, N, H, s));
+  TRY(linear_bwd_weight(w.dH0, d_x, F, G(GVAE_P_CONV1_W), B * N, H, F, w.splitk, s));
+  return check_launch("step_backward");
+}
+
+int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which, float **out_ptr,
+                         int64_t *out_count) {
+  GVAE_REQUIRE(d && d_ws && out_ptr && out_count && n_graphs > 0, GVAE_EINVAL, "read_debug: bad args");
+  const Workspace w = carve(d, n_graphs, (char *)d_ws);
+  const int64_t B = n_graphs, N = d->N, Z = d->Z, U = N * (N - 1) / 2;
+  switch (which) {
+    case 0: *out_ptr = w.vec; *out_count = B * U; break;
+    case 1: *out_ptr = w.node; *out_count = B * N; break;
+    case 2: *out_ptr = w.P; *out_count = B * N * N; break;
+    case 3: *out_ptr = w.X; *out_count = B * N * N; break;
+    case 4: *out_ptr = w.mu; *out_count = B * Z; break;
+    case 5: *out_ptr = w.lvraw; *out_count = B * Z; break;
+    case 6: *out_ptr = w.rec_i; *out_count = B; break;
+    case 7: *out_ptr = w.kl_i; *out_count = B; break;
+    case 8: *out_ptr = reinterpret_cast<float *>(w.status); *out_count = B; break;
+    default: return set_error(GVAE_EINVAL, "read_debug: unknown buffer %d", which);
+  }
+  return GVAE_OK;
+}
+
+int64_t gvae_adam_ws_bytes(void) { return NORM_BLOCKS * sizeof(double); }
+
+int gvae_adam_step(float *d_params, const float *d_grads, float *d_m, float *d_v, int64_t n,
+                   float grad_scale, float clip_max, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, void *d_ws, float *d_norm_out, void *stream) {
+  GVAE_REQUIRE(d_params && d_grads && d_m && d_v && d_ws && n > 0 && step >= 1, GVAE_EINVAL,
+               "adam_step: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  double *partial = (double *)d_ws;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, d_grads, n, grad_scale,
+                     partial);
+  const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)),
+                     dim3(256), 0, s, d_params, d_grads, d_m, d_v, n, grad_scale, clip_max, partial,
+                     step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, d_norm_out);
+  return check_launch("adam_step");
+}
+
+}  // extern "C"

@@ -104,6 +104,91 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
 int gvae_lsap(const float *d_X, int ldx, int64_t strideX, const int32_t *d_R, int n_graphs,
               int r_max, int64_t *d_perm, int n_perm, int32_t *d_status, void *stream);
 
+
+/* ===========================================================================
+ * Whole training step (dense encoder/decoder + matching + losses + optimiser).
+ * =========================================================================== */
+
+/* Model dimensions: in_dim, hid_dim, z_dim, max_nodes of
+ * GraphVAE.__init__, graphvae/models/model.py:63-94. */
+typedef struct gvae_dims {
+  int32_t F, H, Z, N;
+} gvae_dims;
+
+/* Parameter tensors, in the order of the reference module's named_parameters()
+ * (graphvae/models/model.py:71-89; GCNConv registers `bias` before `lin.weight`).
+ * All live in ONE flat fp32 buffer; each tensor starts at a multiple of 4 floats. */
+enum {
+  GVAE_P_CONV1_B, GVAE_P_CONV1_W, GVAE_P_BN1_W, GVAE_P_BN1_B,
+  GVAE_P_CONV2_B, GVAE_P_CONV2_W, GVAE_P_BN2_W, GVAE_P_BN2_B,
+  GVAE_P_MU_W, GVAE_P_MU_B, GVAE_P_LV_W, GVAE_P_LV_B,
+  GVAE_P_DE1_W, GVAE_P_DE1_B, GVAE_P_DE2_W, GVAE_P_DE2_B,
+  GVAE_P_DN1_W, GVAE_P_DN1_B, GVAE_P_DN2_W, GVAE_P_DN2_B,
+  GVAE_P_COUNT
+};
+
+/* Fills offsets[GVAE_P_COUNT] / sizes[GVAE_P_COUNT] (floats; either may be NULL) and
+ * returns the length of the flat buffer in floats (padding included), -1 on bad dims. */
+int64_t gvae_param_layout(const gvae_dims *d, int64_t *offsets, int64_t *sizes);
+
+#define GVAE_MATCH_NONE 0    /* identity permutation, no matching kernels           */
+#define GVAE_MATCH_STREAM 1  /* materialise S, stream it per MPM iteration (HBM)    */
+#define GVAE_MATCH_FUSED 2   /* S-free MPM resident in LDS                          */
+
+/* Bytes of scratch gvae_step_forward/backward need for n_graphs graphs.  The
+ * forward leaves its activations there for the backward of the same batch. */
+int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs);
+
+/* Forward of GraphVAE.forward, graphvae/models/model.py:281-373, for a whole batch.
+ *   d_params     flat parameters (gvae_param_layout)
+ *   d_bn_state   [bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var],
+ *                4*H floats; updated in place when train != 0, graph by graph in batch
+ *                order as the reference's per-graph BatchNorm calls do
+ *   d_x          (n_graphs, N, F) node features, zero rows beyond n_x[g]
+ *   d_adj        (n_graphs, N, N) adj_dense: 0/1, symmetric, unit diagonal on real nodes
+ *   d_n_x        feature rows per graph (N for `deg` features, R for `id`;
+ *                graphvae/train/train_ddp.py:67-78)
+ *   d_R          real nodes per graph;  r_max >= max R (host value)
+ *   d_eps        (n_graphs, Z) standard-normal draws for the reparameterisation
+ *   d_pos_weight 1 float: the pos_weight_global buffer
+ *   matching     GVAE_MATCH_*;  STREAM needs d_S (sum of R^4 floats, 16-byte aligned
+ *                blocks) and d_S_off; both may be NULL otherwise
+ *   d_out4       [rec, kl, max_logit, logvar_max]   (loss = rec + kl)
+ *   d_perm       (n_graphs, N) int64 perm_full per graph;  d_iters_done MPM iterations
+ */
+int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
+                      const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
+                      int r_max, const float *d_eps, const float *d_pos_weight, int train,
+                      int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                      const int64_t *d_S_off, void *d_ws, float *d_out4, int64_t *d_perm,
+                      int32_t *d_iters_done, void *stream);
+
+/* Backward of  c_rec*up[0]*rec + c_kl*up[1]*kl  with respect to every parameter
+ * (what loss.backward() does in graphvae/train/train_ddp.py:283-291, where
+ * c_rec = 1 and c_kl = beta).  d_up may be NULL (= ones) or 2 device floats.
+ * d_ws must be the workspace the forward of this batch just filled.  d_grads is
+ * overwritten (flat, same layout as the parameters; padding floats untouched). */
+int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d_x,
+                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
+                       const float *d_eps, const float *d_pos_weight, float c_rec, float c_kl,
+                       const float *d_up, void *d_ws, float *d_grads, void *stream);
+
+/* Pointer into the workspace for inspection by tests: which = 0 edge logits (B,U),
+ * 1 node logits (B,N), 2 P (B,N,N), 3 X (B,N,N), 4 mu, 5 logvar (pre-clamp) (B,Z),
+ * 6 rec_i, 7 kl_i (B), 8 assignment status (B, int32). */
+int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which, float **out_ptr,
+                         int64_t *out_count);
+
+/* Global-norm clipping + Adam with L2 weight decay on the flat buffers; replaces
+ * clip_grad_norm_ + torch.optim.Adam.step, graphvae/train/train_ddp.py:243,292,316.
+ * Gradients are first multiplied by grad_scale (1/world_size after a SUM all-reduce).
+ * step counts from 1.  clip_max <= 0 disables clipping.  d_norm_out (nullable)
+ * receives the pre-clip gradient norm.  d_ws: gvae_adam_ws_bytes() bytes. */
+int64_t gvae_adam_ws_bytes(void);
+int gvae_adam_step(float *d_params, const float *d_grads, float *d_m, float *d_v, int64_t n,
+                   float grad_scale, float clip_max, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, void *d_ws, float *d_norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

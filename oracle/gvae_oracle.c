@@ -114,7 +114,10 @@ void ora_rowsum(const float *M, int R, int ld, float *out) {
 }
 
 /* 2-norm of n contiguous floats: 8 lane accumulators with fused multiply-add over
- * consecutive chunks of 8, lanes folded 0+1+...+7, scalar tail fused, sqrt.      */
+ * consecutive chunks of 8, lanes folded 0+1+...+7, then the tail of n % 8 elements:
+ * when it has 4 or more elements its first four squares are rounded on their own and
+ * added one by one (the PyTorch CPU build computes them as one 4-wide product), every
+ * other tail element is fused in; finally sqrt.                                    */
 float ora_norm2(const float *x, int64_t n) {
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t d = 0;
@@ -122,6 +125,12 @@ float ora_norm2(const float *x, int64_t n) {
     for (int l = 0; l < 8; ++l) acc[l] = fmaf(x[d + l], x[d + l], acc[l]);
   float s = acc[0];
   for (int l = 1; l < 8; ++l) s = s + acc[l];
+  if (n - d >= 4) {
+    for (int k = 0; k < 4; ++k, ++d) {
+      const float sq = x[d] * x[d];
+      s = s + sq;
+    }
+  }
   for (; d < n; ++d) s = fmaf(x[d], x[d], s);
   return sqrtf(s);
 }

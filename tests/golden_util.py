@@ -1,0 +1,113 @@
+"""Helpers to load the g5_forward_* golden fixtures."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+
+def load_g5(path):
+    g = np.load(path, allow_pickle=False)
+    n = int(g["n_graphs"])
+    graphs, eps, perms, perms_eval, Ps, Xs = [], [], [], [], [], []
+    for i in range(n):
+        graphs.append(SimpleNamespace(
+            x=torch.from_numpy(g[f"g{i}/x"]), edge_index=torch.from_numpy(g[f"g{i}/edge_index"]),
+            adj_dense=torch.from_numpy(g[f"g{i}/adj_dense"]), num_real_nodes=int(g[f"g{i}/R"])))
+        eps.append(torch.from_numpy(g[f"g{i}/eps"]))
+        perms.append(g[f"g{i}/perm"])
+        perms_eval.append(g[f"g{i}/perm_eval"])
+        Ps.append(g[f"g{i}/P"])
+        Xs.append(g[f"g{i}/X"])
+    state0 = {k[len("state0/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state0/")}
+    grads = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    state1 = {k[len("state1/"):]: g[k] for k in g.files if k.startswith("state1/")}
+    out = {k[len("out/"):]: g[k] for k in g.files if k.startswith("out/")}
+    out_eval = {k[len("out_eval/"):]: g[k] for k in g.files if k.startswith("out_eval/")}
+    opt = {"hparams": g["opt/hparams"], "losses": g["opt/losses"],
+           "state3": {k[len("opt/state3/"):]: g[k] for k in g.files if k.startswith("opt/state3/")},
+           "eps": [[torch.from_numpy(g[f"opt/eps{s}_{i}"]) for i in range(n)] for s in range(3)]}
+    dims = dict(N=int(g["N"]), H=int(g["H"]), Z=int(g["Z"]), in_dim=int(g["in_dim"]))
+    return SimpleNamespace(graphs=graphs, eps=eps, perms=perms, perms_eval=perms_eval, P=Ps, X=Xs,
+                           state0=state0,
+                           grads=grads, state1=state1, out=out, out_eval=out_eval, opt=opt, dims=dims,
+                           rho=float(g["rho"]))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+ZERO_GRAD_PARAMS = ("conv1.bias", "conv2.bias")
+
+
+def truth64(G):
+    """Loss and gradients of the golden case recomputed in float64 by the CPU
+    restatement: the yardstick for how far the fp32 reference itself is from the exact
+    answer (BatchNorm over a handful of near-identical rows is ill-conditioned)."""
+    from oracle import ref_step as R
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        st = R.make_trainable({k: (v.double() if v.is_floating_point() else v.clone())
+                               for k, v in G.state0.items()})
+        graphs = [SimpleNamespace(x=g.x.double(), adj_dense=g.adj_dense.double(),
+                                  num_real_nodes=g.num_real_nodes) for g in G.graphs]
+        res = R.forward_batch(st, graphs, [e.double() for e in G.eps], train=True)
+        res.loss.backward()
+        return {n: st[n].grad.numpy().copy() for n in R.PARAM_NAMES}
+    finally:
+        torch.set_default_dtype(old)
+
+
+def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e-5):
+    """Each gradient tensor within `tol` relative (to its largest entry) of the
+    reference's, plus, when `truth` (float64 recomputation) is given, twice the
+    reference's own distance from it -- a result cannot be asked to sit closer to the
+    fp32 reference than that reference sits to the exact value.  The two GCN biases feed
+    straight into a training-mode BatchNorm, which cancels any per-column constant: their
+    true gradient is zero and the reference holds only rounding noise there, so those are
+    only required to be noise (<= 20*tol of the model-wide gradient scale; the reference's
+    own noise reaches 5*tol of it on the grid graphs)."""
+    gmax = max(float(np.abs(v).max()) for v in ref.values())
+    for name, r in ref.items():
+        g = np.asarray(got[name], np.float64)
+        r = np.asarray(r, np.float64)
+        if name in ZERO_GRAD_PARAMS:
+            assert np.abs(g).max() <= 20 * tol * gmax and np.abs(r).max() <= 20 * tol * gmax, name
+            continue
+        slack = 2.0 * float(np.abs(r - truth[name]).max()) if truth is not None else 0.0
+        err = float(np.abs(g - r).max())
+        assert err <= tol * max(np.abs(r).max(), 1e-30) + slack, (name, err, float(np.abs(r).max()), slack)
+
+
+def perm_equivalent(perm, perm_ref, X, tol=1e-5):
+    """True if `perm` equals the reference permutation, or both are optimal for X up to
+    rounding (ties between assignments of near-identical value: an end-to-end run reaches
+    the matching with probabilities that differ from the reference's in the last bits, and
+    on graphs with symmetries that can flip the choice between equally good assignments).
+    perm[a] = row assigned to column a; objective = sum_a X[perm[a], a]."""
+    perm, perm_ref = np.asarray(perm), np.asarray(perm_ref)
+    if np.array_equal(perm, perm_ref):
+        return True
+    r = len(perm_ref)
+    X = np.asarray(X, np.float64)[:r, :r]
+    cols = np.arange(r)
+    v, vr = X[perm[:r], cols].sum(), X[perm_ref, cols].sum()
+    return sorted(perm[:r].tolist()) == list(range(r)) and abs(v - vr) <= tol * abs(vr)
+
+
+def check_params_after_adam(got: dict, ref: dict, lr: float, tol: float = 1e-4):
+    """Parameters after the three golden optimiser steps.  Adam divides each gradient by
+    its own running magnitude, so an entry whose gradient is pure rounding noise (the GCN
+    biases, see check_grads) moves by +-lr per step in a direction set by that noise: those
+    two tensors are only required to stay within 3*lr of the reference.  Everything else
+    must agree to `tol` of the tensor's scale."""
+    for name, r in ref.items():
+        if name not in got:
+            continue
+        g, r = np.asarray(got[name], np.float64), np.asarray(r, np.float64)
+        if name in ZERO_GRAD_PARAMS:
+            assert np.abs(g - r).max() <= 3.0 * lr * 1.01, name
+        else:
+            assert np.abs(g - r).max() <= tol * max(np.abs(r).max(), 1e-3), (name, float(np.abs(g - r).max()))

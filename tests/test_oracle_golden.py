@@ -36,6 +36,15 @@ def test_reduction_orders(golden_dir):
         assert np.array_equal(ora.rowsum(M), g[f"R{R}/rowsum"]), f"sum(1) R={R}"
 
 
+def test_norm_all_tail_lengths(golden_dir):
+    g = _npz(golden_dir, "g7_reduction_orders.npz")
+    lens, vals = g["norm_tail/len"], g["norm_tail/val"]
+    assert set((lens % 8).tolist()) == set(range(8))
+    for k, (n, ref) in enumerate(zip(lens.tolist(), vals)):
+        v = np.random.default_rng(3000 + k).random(n, dtype=np.float32)
+        assert ora.norm2(v) == ref, (k, n)
+
+
 def _names(g):
     return [str(n) for n in g["names"]]
 

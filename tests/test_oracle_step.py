@@ -1,0 +1,71 @@
+"""oracle/ref_step.py (CPU restatement of the whole step) against the golden
+vectors of the imported reference: losses, per-graph permutations, every parameter
+gradient, BatchNorm running statistics, and three optimiser steps.
+Tolerance: 1e-5 relative (north-star bar for loss and gradients); permutations exact."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_step as R
+from oracle import matching as ora
+from golden_util import check_grads, check_params_after_adam, load_g5, perm_equivalent, rel_err, truth64
+
+CASES = ["grid_deg", "grid_id", "rand_deg", "rand_id"]
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_backward_matches_reference(golden_dir, case):
+    G = load_g5(golden_dir / f"g5_forward_{case}.npz")
+    st = R.make_trainable(G.state0)
+    res = R.forward_batch(st, G.graphs, G.eps, train=True)
+    seen = []
+    for k in ("rec", "kl", "loss", "max_logit", "logvar_max"):
+        assert rel_err(getattr(res, k).detach().numpy(), G.out[k]) < TOL, k
+    for o, p, Pref, Xref in zip(res.per_graph, G.perms, G.P, G.X):
+        r = len(p)
+        assert rel_err(o.P[:r, :r].numpy(), Pref) < TOL
+        assert perm_equivalent(o.perm[:r].numpy(), p, o.X.numpy())
+        # matching pinned exactly on the reference's own (A, P): C oracle == reference bits
+        A = G.graphs[len(seen)].adj_dense.numpy()[:r, :r]
+        Xo, _ = ora.mpm_sfree(A, Pref)
+        assert np.array_equal(Xo, Xref)
+        assert np.array_equal(ora.assign_perm(Xo), p)
+        seen.append(r)
+    assert sum(np.array_equal(o.perm[:len(p)].numpy(), p) for o, p in zip(res.per_graph, G.perms)) \
+        >= len(G.perms) - 1
+    res.loss.backward()
+    check_grads({n: st[n].grad.numpy() for n in R.PARAM_NAMES}, G.grads, truth64(G), TOL)
+    for k, v in G.state1.items():
+        assert rel_err(st[k].detach().numpy(), v) < TOL, k
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eval_mode_matches_reference(golden_dir, case):
+    G = load_g5(golden_dir / f"g5_forward_{case}.npz")
+    st = R.make_trainable(G.state0)
+    with torch.no_grad():
+        R.forward_batch(st, G.graphs, G.eps, train=True)      # moves the running stats
+        res = R.forward_batch(st, G.graphs, G.eps, train=False)
+    for k in ("rec", "kl", "loss"):
+        assert rel_err(res.__dict__[k].numpy(), G.out_eval[k]) < TOL, k
+    for o, p in zip(res.per_graph, G.perms_eval):
+        assert perm_equivalent(o.perm[:len(p)].numpy(), p, o.X.numpy())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_three_optimizer_steps(golden_dir, case):
+    """Schedule of reference train_ddp.py:282-292,316."""
+    G = load_g5(golden_dir / f"g5_forward_{case}.npz")
+    lr, wd, beta0, beta_final, clip_max, anneal = G.opt["hparams"].tolist()
+    st = R.make_trainable(G.state0)
+    opt = torch.optim.Adam([st[n] for n in R.PARAM_NAMES], lr=lr, weight_decay=wd)
+    for gs in range(3):
+        loss, res, gn = R.train_step(st, opt, G.graphs, G.opt["eps"][gs], gs, int(anneal), lr, beta0,
+                                     beta_final, clip_max)
+        ref = G.opt["losses"][gs]
+        assert abs(loss - ref[0]) <= 2e-5 * abs(ref[0]), (gs, loss, ref[0])
+        assert abs(gn - ref[3]) <= 1e-4 * abs(ref[3]), (gs, gn, ref[3])
+    check_params_after_adam({k: st[k].detach().numpy() for k in R.PARAM_NAMES}, G.opt["state3"], lr)

@@ -173,6 +173,12 @@ def matching_cases(rng):
         cases.append((f"empty_R{R}", np.eye(R, dtype=np.float32), rand_prob(rng, R), 50, 1e-4, True))
         cases.append((f"generic_constB_R{R}", rand_adj(rng, R, 0.4),
                       np.full((R, R), 0.25, np.float32), 50, 1e-4, True))
+    # grid graphs (symmetric: near-ties in X) as in the reference's `grid` dataset
+    import networkx as nx
+    for a, b in ((2, 3), (3, 3), (2, 2), (4, 5), (5, 6)):
+        Ag = nx.to_numpy_array(nx.grid_2d_graph(a, b), dtype=np.float32)
+        np.fill_diagonal(Ag, 1.0)
+        cases.append((f"grid_{a}x{b}", Ag, rand_prob(rng, a * b, 0.5), 50, 1e-4, True))
     # large: few iterations only (S is R^4 floats in the reference)
     cases.append(("large_R64", rand_adj(rng, 64, 0.1), rand_prob(rng, 64), 50, 1e-4, True))
     cases.append(("large_R65", rand_adj(rng, 65, 0.1), rand_prob(rng, 65), 6, 1e-4, False))
@@ -263,6 +269,15 @@ def gen_reduction_orders(out: Path):
         store[f"R{R}/norm"] = np.float32(torch.from_numpy(Mg).norm(p=2).item())
         store[f"R{R}/rowsum"] = torch.from_numpy(Mg).sum(1).numpy()
     store["Rs"] = np.array(Rs, dtype=np.int64)
+    # norm with every tail length n % 8 (inputs rebuilt in the tests from default_rng(3000+k))
+    lens, vals = [], []
+    for k in range(240):
+        n = 8 * (k % 5) + (k % 8) + (8 if k % 5 == 0 and k % 8 == 0 else 0)
+        v = np.random.default_rng(3000 + k).random(n, dtype=np.float32)
+        lens.append(n)
+        vals.append(np.float32(torch.from_numpy(v).norm(p=2).item()))
+    store["norm_tail/len"] = np.array(lens, dtype=np.int64)
+    store["norm_tail/val"] = np.array(vals, dtype=np.float32)
     np.savez_compressed(out / "g7_reduction_orders.npz", **store)
     print("G7 reduction orders:", len(Rs), "sizes")
 
@@ -313,6 +328,19 @@ def run_reference_step(ref, model, graphs, eps_list, train: bool):
     so graphs are fed one at a time through the `else [data]` branch and the
     per-graph losses are averaged exactly as forward does for a batch)."""
     perms = []
+    captured = {"P": [], "X": []}
+    orig_es, orig_mpm = model._edge_sim_tensor, model._mpm
+
+    def es_spy(A, B):
+        captured["P"].append(B.detach().clone().numpy())
+        return orig_es(A, B)
+
+    def mpm_spy(X0, S, *a, **k):
+        X = orig_mpm(X0, S, *a, **k)
+        captured["X"].append(X.detach().clone().numpy())
+        return X
+
+    model._edge_sim_tensor, model._mpm = es_spy, mpm_spy
     orig_lsa = scipy.optimize.linear_sum_assignment
     orig_randn_like = torch.randn_like
     it = iter(eps_list)
@@ -337,13 +365,15 @@ def run_reference_step(ref, model, graphs, eps_list, train: bool):
     finally:
         scipy.optimize.linear_sum_assignment = orig_lsa
         torch.randn_like = orig_randn_like
+        del model._edge_sim_tensor, model._mpm
     rec = torch.stack([o["rec"] for o in outs]).mean()
     kl = torch.stack([o["kl"] for o in outs]).mean()
     max_logit = torch.stack([o["max_logit"] for o in outs]).max()
     return {"rec": rec, "kl": kl, "loss": rec + kl, "max_logit": max_logit,
             "logvar_max": outs[-1]["logvar_max"],
             "rec_i": torch.stack([o["rec"] for o in outs]).detach(),
-            "kl_i": torch.stack([o["kl"] for o in outs]).detach()}, perms
+            "kl_i": torch.stack([o["kl"] for o in outs]).detach(),
+            "P": captured["P"], "X": captured["X"]}, perms
 
 
 def gen_forward(ref, out: Path):
@@ -382,6 +412,8 @@ def gen_forward(ref, out: Path):
             store[f"g{i}/R"] = np.int64(int(g.num_real_nodes))
             store[f"g{i}/eps"] = eps[i].numpy()
             store[f"g{i}/perm"] = perms[i]
+            store[f"g{i}/P"] = res["P"][i]      # sigmoid(logits)[:R,:R] handed to the matching
+            store[f"g{i}/X"] = res["X"][i]      # its MPM result
         store["n_graphs"] = np.int64(len(graphs))
         for k, v in state0.items():
             store[f"state0/{k}"] = v
