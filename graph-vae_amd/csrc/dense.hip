@@ -162,10 +162,12 @@ int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, 
 // ---------------------------------------------------------------------------
 #define BN_EPS 1e-5f
 
-__device__ __forceinline__ float quad_rows_sum(float v, float (*sh)[64], int rl, int c) {
+// Column statistics are accumulated in double, as PyTorch's CPU BatchNorm does
+// (its accumulation type for float is double), then rounded to fp32 once.
+__device__ __forceinline__ double quad_rows_sum(double v, double (*sh)[64], int rl, int c) {
   sh[rl][c] = v;
   __syncthreads();
-  const float t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  const double t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
   __syncthreads();
   return t;
 }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
     const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
     float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
     float *__restrict__ var_unb_o) {
-  __shared__ float sh[4][64];
+  __shared__ double sh[4][64];
   const int g = blockIdx.y, tid = threadIdx.x;
   const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
   const bool cv = c < H;
@@ -186,22 +188,22 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
   const float b = cv ? bias[c] : 0.0f;
   float mean, invstd;
   if (train) {
-    float s = 0.0f;
-    if (cv) for (int i = rl; i < nx; i += 4) s += Yg[(int64_t)i * H + c] + b;
+    double s = 0.0;
+    if (cv) for (int i = rl; i < nx; i += 4) s += (double)(Yg[(int64_t)i * H + c] + b);
     s = quad_rows_sum(s, sh, rl, cl);
-    mean = s / (float)nx;
-    float q = 0.0f;
+    const double mean_d = s / (double)nx;
+    double q = 0.0;
     if (cv) for (int i = rl; i < nx; i += 4) {
-      const float dlt = (Yg[(int64_t)i * H + c] + b) - mean;
+      const double dlt = (double)(Yg[(int64_t)i * H + c] + b) - mean_d;
       q += dlt * dlt;
     }
     q = quad_rows_sum(q, sh, rl, cl);
-    const float var = q / (float)nx;
-    invstd = 1.0f / sqrtf(var + BN_EPS);
+    mean = (float)mean_d;
+    invstd = (float)(1.0 / sqrt(q / (double)nx + (double)BN_EPS));
     if (cv && rl == 0) {
       mean_o[(int64_t)g * H + c] = mean;
       invstd_o[(int64_t)g * H + c] = invstd;
-      var_unb_o[(int64_t)g * H + c] = q / (float)(nx - 1);
+      var_unb_o[(int64_t)g * H + c] = (float)(q / (double)(nx - 1));
     }
   } else {
     mean = cv ? run_mean[c] : 0.0f;
@@ -256,16 +258,17 @@ int launch_bn_running_update(const float *mean, const float *var_unb, int B, int
   return check_launch("bn_running_update");
 }
 
-// backward of relu(BN(Y + bias)) in training mode:
-//   dpre = dOut * (out > 0);  dbeta = sum dpre;  dgamma = sum dpre * xhat
-//   dY = gamma * invstd * (dpre - dbeta/n - xhat * dgamma/n)   (rows >= n_x: 0)
+// backward of relu(BN(Y + bias)) in training mode (sums in double):
+//   dpre = dOut * (out > 0);  dbeta = sum dpre;  dot = sum dpre * (y - mean)
+//   dgamma = dot * invstd;   dY = (dpre - dbeta/n - (y - mean) * dot * invstd^2 / n) * invstd * gamma
+//   rows >= n_x: 0
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     const float *__restrict__ dOut, const float *__restrict__ Y, const float *__restrict__ bias,
     const float *__restrict__ out, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ invstd, const int32_t *__restrict__ n_x, int N, int H,
     float *__restrict__ dY, float *__restrict__ dgamma_p, float *__restrict__ dbeta_p,
     float *__restrict__ dbias_p) {
-  __shared__ float sh[4][64];
+  __shared__ double sh[4][64];
   const int g = blockIdx.y, tid = threadIdx.x;
   const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
   const bool cv = c < H;
@@ -274,36 +277,35 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   const float b = cv ? bias[c] : 0.0f;
   const float mu = cv ? mean[(int64_t)g * H + c] : 0.0f;
   const float is = cv ? invstd[(int64_t)g * H + c] : 0.0f;
-  float sb = 0.0f, sg = 0.0f;
+  double sb = 0.0, dot = 0.0;
   if (cv) for (int i = rl; i < nx; i += 4) {
     const int64_t e = base + (int64_t)i * H + c;
     const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
-    const float xh = ((Y[e] + b) - mu) * is;
-    sb += dp;
-    sg += dp * xh;
+    sb += (double)dp;
+    dot += (double)dp * (double)((Y[e] + b) - mu);
   }
   sb = quad_rows_sum(sb, sh, rl, cl);
-  sg = quad_rows_sum(sg, sh, rl, cl);
+  dot = quad_rows_sum(dot, sh, rl, cl);
   const float ga = cv ? gamma[c] : 0.0f;
-  const float inv_n = 1.0f / (float)nx;
-  float sdy = 0.0f;
+  const float dmean = (float)(sb / (double)nx);
+  const float k = (float)(dot * (double)is * (double)is / (double)nx);
+  double sdy = 0.0;
   if (cv) for (int i = rl; i < N; i += 4) {
     const int64_t e = base + (int64_t)i * H + c;
     float v = 0.0f;
     if (i < nx) {
       const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
-      const float xh = ((Y[e] + b) - mu) * is;
-      v = ga * is * (dp - sb * inv_n - xh * sg * inv_n);
+      const float xc = (Y[e] + b) - mu;
+      v = (dp - dmean - xc * k) * is * ga;
     }
     dY[e] = v;
-    sdy += v;
+    sdy += (double)v;
   }
-  sh[rl][cl] = sdy;
-  __syncthreads();
+  sdy = quad_rows_sum(sdy, sh, rl, cl);
   if (rl == 0 && cv) {
-    dgamma_p[(int64_t)g * H + c] = sg;
-    dbeta_p[(int64_t)g * H + c] = sb;
-    dbias_p[(int64_t)g * H + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    dgamma_p[(int64_t)g * H + c] = (float)(dot * (double)is);
+    dbeta_p[(int64_t)g * H + c] = (float)sb;
+    dbias_p[(int64_t)g * H + c] = (float)sdy;
   }
 }
 

@@ -373,6 +373,14 @@ int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which
     case 6: *out_ptr = w.rec_i; *out_count = B; break;
     case 7: *out_ptr = w.kl_i; *out_count = B; break;
     case 8: *out_ptr = reinterpret_cast<float *>(w.status); *out_count = B; break;
+    case 9: *out_ptr = w.Y1; *out_count = B * N * d->H; break;
+    case 10: *out_ptr = w.H1; *out_count = B * N * d->H; break;
+    case 11: *out_ptr = w.Y2; *out_count = B * N * d->H; break;
+    case 12: *out_ptr = w.H2; *out_count = B * N * d->H; break;
+    case 13: *out_ptr = w.gvec; *out_count = B * d->H; break;
+    case 14: *out_ptr = w.Ahat; *out_count = B * N * N; break;
+    case 15: *out_ptr = w.dY; *out_count = B * N * d->H; break;
+    case 16: *out_ptr = w.dgvec; *out_count = B * d->H; break;
     default: return set_error(GVAE_EINVAL, "read_debug: unknown buffer %d", which);
   }
   return GVAE_OK;

@@ -1,0 +1,221 @@
+"""Host-side sequencing of the HIP training step (ctypes calls into libgvae_hip.so).
+
+torch owns the device buffers and the stream; every computation is a HIP kernel
+behind the C ABI of include/gvae_hip.h.  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+from . import _hip
+from .data import DenseGraphBatch
+
+P_COUNT = 20
+MATCH_NONE, MATCH_STREAM, MATCH_FUSED = 0, 1, 2
+_MATCH = {"none": MATCH_NONE, "stream": MATCH_STREAM, "fused": MATCH_FUSED}
+
+# parameter tensors in flat-buffer order (reference module named_parameters() order)
+PARAM_NAMES = [
+    "conv1.bias", "conv1.lin.weight", "bn1.weight", "bn1.bias",
+    "conv2.bias", "conv2.lin.weight", "bn2.weight", "bn2.bias",
+    "mu.weight", "mu.bias", "logvar.weight", "logvar.bias",
+    "dec_edge.0.weight", "dec_edge.0.bias", "dec_edge.2.weight", "dec_edge.2.bias",
+    "dec_node.0.weight", "dec_node.0.bias", "dec_node.2.weight", "dec_node.2.bias",
+]
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [("F", c_int32), ("H", c_int32), ("Z", c_int32), ("N", c_int32)]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = _hip.lib()
+    if _bound:
+        return L
+    L.gvae_param_layout.argtypes = [POINTER(Dims), POINTER(c_int64), POINTER(c_int64)]
+    L.gvae_param_layout.restype = c_int64
+    L.gvae_step_ws_bytes.argtypes = [POINTER(Dims), c_int]
+    L.gvae_step_ws_bytes.restype = c_int64
+    L.gvae_step_forward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]
+    L.gvae_step_backward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]
+    L.gvae_step_read_debug.argtypes = [POINTER(Dims), c_int, c_void_p, c_int, POINTER(c_void_p),
+                                       POINTER(c_int64)]
+    L.gvae_adam_ws_bytes.restype = c_int64
+    L.gvae_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
+                                 c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p,
+                                 c_void_p, c_void_p]
+    _bound = True
+    return L
+
+
+def param_layout(F: int, H: int, Z: int, N: int):
+    """(offsets, sizes, total) of the flat parameter buffer, in floats."""
+    L = _bind()
+    d = Dims(F, H, Z, N)
+    off = (c_int64 * P_COUNT)()
+    size = (c_int64 * P_COUNT)()
+    tot = L.gvae_param_layout(ctypes.byref(d), off, size)
+    if tot < 0:
+        raise _hip.GvaeHipError(f"bad model dimensions F={F} H={H} Z={Z} N={N}")
+    return list(off), list(size), int(tot)
+
+
+class StepEngine:
+    """Runs forward / backward / optimiser of one GraphVAE step for batches of up to any
+    size; scratch is grown on demand and reused."""
+
+    def __init__(self, F: int, H: int, Z: int, N: int, device, matching: str = "auto",
+                 mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True):
+        self.L = _bind()
+        self.dims = Dims(F, H, Z, N)
+        self.F, self.H, self.Z, self.N = F, H, Z, N
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _hip.GvaeHipError("the GraphVAE HIP step needs a GPU device (no CPU fallback)")
+        if matching not in ("auto", "none", "stream", "fused"):
+            raise ValueError("matching must be auto | none | stream | fused")
+        self.matching = matching
+        self.mpm_iters, self.tol, self.early_stop = int(mpm_iters), float(tol), bool(early_stop)
+        self._ws = None
+        self._ws_graphs = 0
+        self._S = None
+        self._S_off = None
+        self._S_key = None
+        self._adam_ws = torch.empty(self.L.gvae_adam_ws_bytes(), dtype=torch.uint8, device=self.device)
+        self.out4 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.perm = None
+        self.iters_done = None
+        self.generation = 0
+        self._fwd_batch = None
+
+    # ------------------------------------------------------------------ helpers
+    def _ensure(self, B: int) -> None:
+        if self._ws is None or B > self._ws_graphs:
+            need = self.L.gvae_step_ws_bytes(ctypes.byref(self.dims), B)
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_graphs = B
+        if self.perm is None or self.perm.shape[0] != B:
+            self.perm = torch.empty(B, self.N, dtype=torch.int64, device=self.device)
+            self.iters_done = torch.empty(B, dtype=torch.int32, device=self.device)
+
+    def resolve_matching(self, r_max: int) -> int:
+        if self.matching == "auto":
+            return MATCH_FUSED if _hip.mpm_fused_supported(r_max) else MATCH_STREAM
+        return _MATCH[self.matching]
+
+    def _ensure_S(self, r_host) -> None:
+        key = tuple(r_host)
+        if key == self._S_key:
+            return
+        offs, tot = _hip.s_offsets(r_host)
+        if self._S is None or self._S.numel() < tot:
+            self._S = torch.empty(max(tot, 4), dtype=torch.float32, device=self.device)
+        self._S_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        self._S_key = key
+
+    def _check_batch(self, b: DenseGraphBatch) -> None:
+        B, N, F = b.x.shape
+        if N != self.N or F != self.F or tuple(b.adj_dense.shape) != (B, N, N):
+            raise _hip.GvaeHipError(
+                f"batch shapes x={tuple(b.x.shape)} adj={tuple(b.adj_dense.shape)} do not match the "
+                f"model (max_nodes={self.N}, in_dim={self.F})")
+        for t, dt in ((b.x, torch.float32), (b.adj_dense, torch.float32), (b.n_x, torch.int32),
+                      (b.num_real_nodes, torch.int32)):
+            _hip._dev(t, dt)
+        if len(b.r_host) != B or min(b.r_host) < 1 or max(b.r_host) > N:
+            raise _hip.GvaeHipError("batch.r_host must list 1 <= R <= max_nodes for every graph")
+
+    # ------------------------------------------------------------------ step pieces
+    def forward(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,
+                eps: torch.Tensor, pos_weight: torch.Tensor, train: bool) -> torch.Tensor:
+        """Runs the forward; returns the device tensor [rec, kl, max_logit, logvar_max]
+        (a view of engine memory, overwritten by the next forward)."""
+        self._check_batch(batch)
+        B = batch.num_graphs
+        self._ensure(B)
+        _hip._dev(params, torch.float32), _hip._dev(bn_state, torch.float32)
+        _hip._dev(eps, torch.float32), _hip._dev(pos_weight, torch.float32)
+        if tuple(eps.shape) != (B, self.Z):
+            raise _hip.GvaeHipError(f"eps must be ({B}, {self.Z})")
+        r_max = max(batch.r_host)
+        mode = self.resolve_matching(r_max)
+        S_ptr, Soff_ptr = None, None
+        if mode == MATCH_STREAM:
+            self._ensure_S(batch.r_host)
+            S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()
+        _hip._check(self.L.gvae_step_forward(
+            ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
+            batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B, r_max,
+            eps.data_ptr(), pos_weight.data_ptr(), int(train), mode, self.mpm_iters, self.tol,
+            int(self.early_stop), S_ptr, Soff_ptr, self._ws.data_ptr(), self.out4.data_ptr(),
+            self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
+        self.generation += 1
+        self._fwd_batch = (batch, eps)
+        self.last_mode = mode
+        return self.out4
+
+    def backward(self, params: torch.Tensor, pos_weight: torch.Tensor, grads: torch.Tensor,
+                 c_rec: float = 1.0, c_kl: float = 1.0, d_up: torch.Tensor | None = None) -> None:
+        """Gradients of c_rec*up[0]*rec + c_kl*up[1]*kl into the flat `grads` buffer, for the
+        batch of the most recent forward."""
+        if self._fwd_batch is None:
+            raise _hip.GvaeHipError("backward called before forward")
+        batch, eps = self._fwd_batch
+        _hip._dev(grads, torch.float32)
+        up = None
+        if d_up is not None:
+            _hip._dev(d_up, torch.float32)
+            up = d_up.data_ptr()
+        _hip._check(self.L.gvae_step_backward(
+            ctypes.byref(self.dims), params.data_ptr(), batch.x.data_ptr(), batch.adj_dense.data_ptr(),
+            batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), batch.num_graphs, eps.data_ptr(),
+            pos_weight.data_ptr(), float(c_rec), float(c_kl), up, self._ws.data_ptr(),
+            grads.data_ptr(), _hip._stream()))
+
+    def adam_step(self, params, grads, m, v, step: int, lr: float, betas=(0.9, 0.999),
+                  eps: float = 1e-8, weight_decay: float = 0.0, clip_max: float = 0.0,
+                  grad_scale: float = 1.0, norm_out: torch.Tensor | None = None) -> None:
+        n = params.numel()
+        for t in (params, grads, m, v):
+            _hip._dev(t, torch.float32)
+            if t.numel() != n:
+                raise _hip.GvaeHipError("adam_step: flat buffers differ in length")
+        _hip._check(self.L.gvae_adam_step(
+            params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(grad_scale),
+            float(clip_max), float(lr), float(betas[0]), float(betas[1]), float(eps),
+            float(weight_decay), int(step), self._adam_ws.data_ptr(),
+            norm_out.data_ptr() if norm_out is not None else None, _hip._stream()))
+
+    # ------------------------------------------------------------------ inspection (tests)
+    _DEBUG = {"vec_logits": 0, "node_logits": 1, "P": 2, "X": 3, "mu": 4, "logvar_raw": 5, "rec_i": 6,
+              "kl_i": 7, "status": 8, "Y1": 9, "H1": 10, "Y2": 11, "H2": 12, "gvec": 13, "Ahat": 14,
+              "dY1": 15, "dgvec": 16}
+
+    def debug_tensor(self, name: str, B: int) -> torch.Tensor:
+        """Copy of an intermediate buffer of the last forward of B graphs."""
+        ptr, cnt = c_void_p(), c_int64()
+        _hip._check(self.L.gvae_step_read_debug(ctypes.byref(self.dims), B, self._ws.data_ptr(),
+                                                self._DEBUG[name], ctypes.byref(ptr), ctypes.byref(cnt)))
+        off = ptr.value - self._ws.data_ptr()
+        raw = self._ws[off: off + cnt.value * 4]
+        if name == "status":
+            return raw.view(torch.int32).clone()
+        t = raw.view(torch.float32).clone()
+        N, Z = self.N, self.Z
+        shapes = {"vec_logits": (B, N * (N - 1) // 2), "node_logits": (B, N), "P": (B, N, N),
+                  "X": (B, N, N), "mu": (B, Z), "logvar_raw": (B, Z), "rec_i": (B,), "kl_i": (B,),
+                  "Y1": (B, N, self.H), "H1": (B, N, self.H), "Y2": (B, N, self.H), "H2": (B, N, self.H),
+                  "gvec": (B, self.H), "Ahat": (B, N, N), "dY1": (B, N, self.H), "dgvec": (B, self.H)}
+        return t.view(shapes[name])

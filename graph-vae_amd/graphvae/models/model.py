@@ -1,0 +1,324 @@
+"""GraphVAE with the reference's model API, running on hand-written HIP kernels.
+
+Drop-in surface (reference graphvae/models/model.py):
+  GraphVAE(in_dim, hid_dim, z_dim, max_nodes, *, pool="sum")          :63-94
+  .precompute_dataset_rho(loader)                                       :99-118
+  .forward(data) -> {"rec","kl","loss","max_logit","logvar_max"}        :281-373
+  ._edge_sim_tensor(A, B) -> (R,R,R,R)                                  :171-216
+  ._mpm(X0, S, iters=50, tol=1e-4, early_stop=True) -> (R,R)            :247-276
+  ._reparam(mu, logvar), vec_to_adj(vec, N, diag=False), deg_sim(d1, d2)
+State-dict keys are the reference's (conv{1,2}.{bias,lin.weight}, bn{1,2}.*, mu.*,
+logvar.*, dec_edge.{0,2}.*, dec_node.{0,2}.*, pos_weight_global), so checkpoints move
+between the two implementations.
+
+All parameters live in one flat fp32 device buffer (the module's Parameters are views
+into it); the whole batch goes through libgvae_hip.so in a handful of C calls instead
+of the reference's per-graph Python loop.  Gradients come back as views of one flat
+buffer, ready for a single RCCL all-reduce.  There is no CPU path: `forward` raises if
+the model or the data is not on a GPU.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..data import DenseGraphBatch, as_dense_batch
+from ..engine import PARAM_NAMES, StepEngine, param_layout
+
+
+def vec_to_adj(vec: torch.Tensor, N: int, *, diag: bool = False) -> torch.Tensor:
+    """Upper-triangular off-diagonal vector (row-major pair order) -> symmetric (N,N);
+    also accepts a leading batch dimension.  Reference model.py:42-51."""
+    iu = torch.triu_indices(N, N, offset=1, device=vec.device)
+    out = vec.new_zeros(vec.shape[:-1] + (N, N))
+    out[..., iu[0], iu[1]] = vec
+    out = out + out.transpose(-1, -2)
+    if diag:
+        d = torch.arange(N, device=vec.device)
+        out[..., d, d] = 1.0
+    return out
+
+
+def deg_sim(d1, d2):
+    """1 / (|d1 - d2| + 1).  Reference model.py:54-56."""
+    return (torch.abs(d1 - d2) + 1.0).reciprocal()
+
+
+class _WeightOnly(nn.Module):
+    """`lin` of a GCN layer: a weight matrix without bias (state-dict key `lin.weight`)."""
+
+    def __init__(self, in_dim: int, out_dim: int) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
+
+    def forward(self, x):
+        return x @ self.weight.t()
+
+
+class DenseGCNConv(nn.Module):
+    """Parameter holder with PyG GCNConv's state-dict layout (`bias`, `lin.weight`).
+    The training step never calls this module; `forward` is a dense convenience for
+    inspecting a layer outside the step (self loop on every row, D^-1/2 (A+I) D^-1/2)."""
+
+    def __init__(self, in_dim: int, out_dim: int) -> None:
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.lin = _WeightOnly(in_dim, out_dim)
+
+    def forward(self, x, adj):
+        a = (adj != 0).to(x.dtype)
+        eye = torch.eye(a.shape[-1], dtype=x.dtype, device=x.device)
+        a = a * (1 - eye) + eye
+        dinv = a.sum(-1).rsqrt()
+        return (dinv.unsqueeze(-1) * a * dinv.unsqueeze(-2)) @ self.lin(x) + self.bias
+
+
+class _StepFunction(torch.autograd.Function):
+    """Autograd bridge: forward and backward both run inside libgvae_hip.so."""
+
+    @staticmethod
+    def forward(ctx, model, batch, eps, *params):
+        eng = model._engine_for(batch)
+        out4 = eng.forward(model._flat, model._bn_state, batch, eps, model._pos_weight_dev(),
+                           model.training).clone()
+        ctx.model, ctx.engine, ctx.generation = model, eng, eng.generation
+        rec, kl, max_logit, logvar_max = out4[0], out4[1], out4[2], out4[3]
+        ctx.mark_non_differentiable(max_logit, logvar_max)
+        return rec, kl, max_logit, logvar_max
+
+    @staticmethod
+    def backward(ctx, d_rec, d_kl, _d_ml, _d_lv):
+        model, eng = ctx.model, ctx.engine
+        if eng.generation != ctx.generation:
+            raise RuntimeError("GraphVAE: backward() after another forward(); the step keeps the "
+                               "activations of the most recent forward only")
+        up = torch.stack([d_rec if d_rec is not None else torch.zeros_like(eng.out4[0]),
+                          d_kl if d_kl is not None else torch.zeros_like(eng.out4[0])]).contiguous()
+        grads = model._grad_flat_buffer()
+        eng.backward(model._flat, model._pos_weight_dev(), grads, 1.0, 1.0, up)
+        views = model._views_of(grads)
+        return (None, None, None) + tuple(views)
+
+
+class GraphVAE(nn.Module):
+    def __init__(self, in_dim: int, hid_dim: int, z_dim: int, max_nodes: int, *, pool: str = "sum",
+                 matching: str = "auto", mpm_iters: int = 50, mpm_tol: float = 1e-4,
+                 mpm_early_stop: bool = True) -> None:
+        super().__init__()
+        self.in_dim, self.hid_dim, self.z_dim = int(in_dim), int(hid_dim), int(z_dim)
+        self.max_nodes = int(max_nodes)
+        self.pool = pool
+        self.matching = matching
+        self.mpm_iters, self.mpm_tol, self.mpm_early_stop = mpm_iters, mpm_tol, mpm_early_stop
+
+        pairs = self.max_nodes * (self.max_nodes - 1) // 2
+        self.conv1 = DenseGCNConv(in_dim, hid_dim)
+        self.bn1 = nn.BatchNorm1d(hid_dim)
+        self.conv2 = DenseGCNConv(hid_dim, hid_dim)
+        self.bn2 = nn.BatchNorm1d(hid_dim)
+        self.mu = nn.Linear(hid_dim, z_dim)
+        self.logvar = nn.Linear(hid_dim, z_dim)
+        self.dec_edge = nn.Sequential(nn.Linear(z_dim, hid_dim), nn.ReLU(), nn.Linear(hid_dim, pairs))
+        self.dec_node = nn.Sequential(nn.Linear(z_dim, hid_dim), nn.ReLU(), nn.Linear(hid_dim, max_nodes))
+        self.register_buffer("pos_weight_global", torch.tensor(1.0))
+        self.rho_global: float | None = None
+
+        self._init_weights()
+        self._offsets, self._sizes, self._flat_len = None, None, None
+        self._flat = None
+        self._bn_state = None
+        self._grad_flat = None
+        self._engine = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ parameters
+    def _init_weights(self) -> None:
+        """Xavier-uniform with ReLU gain on every weight matrix, zero biases, BatchNorm
+        gamma 1 / beta 0 (reference model.py:123-134)."""
+        gain = math.sqrt(2.0)
+        for name, p in self.named_parameters():
+            if name.startswith("bn"):
+                (nn.init.ones_ if name.endswith("weight") else nn.init.zeros_)(p)
+            elif p.dim() == 2:
+                nn.init.xavier_uniform_(p, gain=gain)
+            else:
+                nn.init.zeros_(p)
+
+    def _named_param_list(self):
+        byname = dict(self.named_parameters())
+        return [byname[n] for n in PARAM_NAMES]
+
+    def _layout(self):
+        if self._offsets is None:
+            if _hip.lib_path().exists():
+                self._offsets, self._sizes, self._flat_len = param_layout(
+                    self.in_dim, self.hid_dim, self.z_dim, self.max_nodes)
+            else:  # lets the module be built (e.g. to inspect a checkpoint) without the library
+                sizes = [p.numel() for p in self._named_param_list()]
+                offs, tot = [], 0
+                for s in sizes:
+                    offs.append(tot)
+                    tot += (s + 3) // 4 * 4
+                self._offsets, self._sizes, self._flat_len = offs, sizes, tot
+        return self._offsets, self._sizes, self._flat_len
+
+    def _views_of(self, flat: torch.Tensor):
+        offs, sizes, _ = self._layout()
+        return [flat[o:o + s].view(p.shape) for o, s, p in zip(offs, sizes, self._named_param_list())]
+
+    def _flatten(self) -> None:
+        """(Re)build the flat parameter / BatchNorm-state buffers on the parameters' current
+        device and make every Parameter and running statistic a view of them."""
+        offs, sizes, tot = self._layout()
+        params = self._named_param_list()
+        dev = params[0].device
+        flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        for view, p in zip(self._views_of(flat), params):
+            view.copy_(p.data)
+            p.data = view
+        H = self.hid_dim
+        bn = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        for k, (mod, key) in enumerate(((self.bn1, "running_mean"), (self.bn1, "running_var"),
+                                        (self.bn2, "running_mean"), (self.bn2, "running_var"))):
+            view = bn[k * H:(k + 1) * H]
+            view.copy_(mod._buffers[key])
+            mod._buffers[key] = view
+        self._flat, self._bn_state = flat, bn
+        self._grad_flat = None
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The single fp32 buffer all parameters are views of."""
+        return self._flat
+
+    def bn_state(self) -> torch.Tensor:
+        """[bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var] flat."""
+        return self._bn_state
+
+    def _grad_flat_buffer(self) -> torch.Tensor:
+        if self._grad_flat is None or self._grad_flat.device != self._flat.device:
+            self._grad_flat = torch.zeros_like(self._flat)
+        return self._grad_flat
+
+    def _pos_weight_dev(self) -> torch.Tensor:
+        return self.pos_weight_global.reshape(1)
+
+    def _engine_for(self, batch: DenseGraphBatch) -> StepEngine:
+        dev = self._flat.device
+        if dev.type != "cuda":
+            raise _hip.GvaeHipError("GraphVAE runs on the GPU only: move the model with .to('cuda')")
+        if batch.device != dev:
+            raise _hip.GvaeHipError(f"batch on {batch.device}, model on {dev}")
+        if self._engine is None:
+            self._engine = StepEngine(self.in_dim, self.hid_dim, self.z_dim, self.max_nodes, dev,
+                                      matching=self.matching, mpm_iters=self.mpm_iters,
+                                      tol=self.mpm_tol, early_stop=self.mpm_early_stop)
+        return self._engine
+
+    # ------------------------------------------------------------------ dataset statistics
+    @torch.no_grad()
+    def precompute_dataset_rho(self, loader) -> None:
+        """Edge density over the upper triangles of all real-node blocks and the clipped
+        positive weight (1-rho)/(rho+1e-8) in [1, 20].  Reference model.py:99-118."""
+        pos_edges, total_pairs = 0.0, 0.0
+        for data in loader:
+            b = as_dense_batch(data, self.max_nodes)
+            N = b.max_nodes
+            idx = torch.arange(N, device=b.device)
+            real = idx.view(1, N) < b.num_real_nodes.view(-1, 1)
+            mask = real.unsqueeze(2) & real.unsqueeze(1) & (idx.view(1, N, 1) < idx.view(1, 1, N))
+            pos_edges += float((b.adj_dense * mask).sum(dtype=torch.float64))
+            total_pairs += sum(r * (r - 1) / 2 for r in b.r_host)
+        rho = pos_edges / (total_pairs + 1e-8)
+        w = float(np.clip((1 - rho) / (rho + 1e-8), 1.0, 20.0))
+        self.rho_global = rho
+        self.pos_weight_global.fill_(w)
+        print(f"[GraphVAE] rho(dataset) = {rho:.4f}  ->  pos_weight = {w:.3f}")
+
+    # ------------------------------------------------------------------ helpers of the API
+    @staticmethod
+    def _reparam(mu, logvar):
+        """mu + eps * exp(logvar / 2).  Reference model.py:137-139."""
+        return mu + torch.randn_like(logvar) * torch.exp(0.5 * logvar)
+
+    def _hip_device(self, *tensors) -> torch.device:
+        for t in tensors:
+            if t.is_cuda:
+                return t.device
+        if self._flat.is_cuda:
+            return self._flat.device
+        if torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        raise _hip.GvaeHipError("the matching kernels need a GPU (no CPU fallback)")
+
+    @torch.no_grad()
+    def _edge_sim_tensor(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """(R,R,R,R) edge-similarity tensor, R = number of rows of A with positive sum.
+        Same values, bit for bit, as reference model.py:171-216; returned on A's device."""
+        dev = self._hip_device(A, B)
+        Ad = A.detach().to(dev, torch.float32)
+        Bd = B.detach().to(dev, torch.float32)
+        R = int((Ad.sum(1) > 0).sum())
+        if R == 0:
+            return A.new_zeros(0, 0, 0, 0, dtype=torch.float32)
+        Ad = Ad[:R, :R].contiguous().unsqueeze(0)
+        Bd = Bd[:R, :R].contiguous().unsqueeze(0)
+        Rt = torch.tensor([R], dtype=torch.int32, device=dev)
+        NS = _hip.node_sim(Ad, Bd, Rt)
+        S, _ = _hip.edge_sim(Ad, Bd, NS, Rt, [R])
+        return S[: R ** 4].view(R, R, R, R).to(A.device)
+
+    @torch.no_grad()
+    def _mpm(self, X0: torch.Tensor, S: torch.Tensor, iters: int = 50, tol: float = 1e-4,
+             early_stop: bool = True) -> torch.Tensor:
+        """Max-pool matching on an explicit S (any non-negative tensor), bit-identical to
+        reference model.py:247-276.  The result carries no autograd history (in `forward`
+        the reference detaches it before use, model.py:319)."""
+        dev = self._hip_device(X0, S)
+        R = X0.shape[0]
+        if tuple(S.shape) != (R, R, R, R):
+            raise ValueError(f"S must be ({R},{R},{R},{R}), got {tuple(S.shape)}")
+        X = X0.detach().to(dev, torch.float32).clone().contiguous().unsqueeze(0)
+        Sd = S.detach().to(dev, torch.float32).contiguous().view(-1)
+        Rt = torch.tensor([R], dtype=torch.int32, device=dev)
+        off = torch.zeros(1, dtype=torch.int64, device=dev)
+        _hip.mpm_stream(Sd, off, Rt, R, X, iters, tol, early_stop)
+        return X[0].to(X0.device)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data):
+        """Training / validation forward of a whole batch.  `data`: DenseGraphBatch, a list
+        of graph records, an object with to_data_list() or one graph record, on the model's
+        GPU.  Returns 0-dim tensors; rec / kl / loss are differentiable w.r.t. the parameters."""
+        if self.rho_global is None:
+            raise RuntimeError("Call `model.precompute_dataset_rho(...)` first!")
+        batch = as_dense_batch(data, self.max_nodes)
+        eps = torch.randn(batch.num_graphs, self.z_dim, dtype=torch.float32, device=batch.device)
+        return self.forward_with_eps(batch, eps)
+
+    def forward_with_eps(self, batch: DenseGraphBatch, eps: torch.Tensor) -> dict:
+        """`forward` with caller-supplied reparameterisation noise (one row per graph)."""
+        if self.rho_global is None:
+            raise RuntimeError("Call `model.precompute_dataset_rho(...)` first!")
+        rec, kl, max_logit, logvar_max = _StepFunction.apply(self, batch, eps, *self._named_param_list())
+        if self.training:
+            for bn in (self.bn1, self.bn2):
+                bn.num_batches_tracked += batch.num_graphs
+        return {"rec": rec, "kl": kl, "loss": rec + kl, "max_logit": max_logit,
+                "logvar_max": logvar_max}
+
+    def last_permutations(self) -> torch.Tensor:
+        """perm_full of every graph of the most recent forward, (B, max_nodes) int64."""
+        return self._engine.perm.clone()
+
+    def last_mpm_iterations(self) -> torch.Tensor:
+        return self._engine.iters_done.clone()

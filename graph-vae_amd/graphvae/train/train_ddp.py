@@ -1,0 +1,425 @@
+#!/usr/bin/env python
+"""Data-parallel GraphVAE training on MI355X: one process per GPU, graph batches
+sharded across ranks, one RCCL all-reduce of the flat gradient buffer per step.
+
+Entry points mirror the reference trainer (graphvae/train/train_ddp.py):
+  python -m graphvae.train.train_ddp --dataset {grid,enzymes,synthetic-dense,synthetic-enzymes}
+         --feature_type {id,deg} [--epochs E] [--max_nodes M] [--log_dir D] [--config Y]
+         [--no_wandb] [--run_name S] [--debug] [--lr LR] [--batch_size B]        (:426-451)
+  train(cfg)                      dict / Namespace, YAML `trainer:` section        (:368-421)
+  GraphDataset(graphs, max_nodes, feature_type)                                   (:57-112)
+  build_graph_list(dataset, max_nodes) -> (graphs, max_nodes)                     (:132-149)
+Outputs `log_dir/params.yaml` and `log_dir/graphvae_ddp.pt` (state_dict with the
+reference's keys).  Under torchrun (RANK / WORLD_SIZE in the environment) each process
+drives the GPU LOCAL_RANK; otherwise one worker per visible GPU is spawned.
+
+Differences from the reference, on purpose: `--epochs` / `--lr` / `--batch_size` are
+accepted on the command line (the reference's own job script passes `--epochs`, which its
+parser rejects); rho / pos_weight reach every rank (the reference computes them on rank 0
+only, after which other ranks cannot run forward); TensorBoard and W&B are optional.
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import os
+import random
+from datetime import datetime
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+from ..data import (DenseGraphBatch, DenseLoader, GraphData, collate, graph_from_adjacency,
+                    graph_from_networkx, synthetic_adjacencies)
+from ..models.model import GraphVAE
+
+SEED = 42
+
+
+def _set_seed() -> None:
+    random.seed(SEED)
+    np.random.seed(SEED)
+    torch.manual_seed(SEED)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(SEED)
+
+
+# --------------------------------------------------------------------------- data
+class GraphDataset(torch.utils.data.Dataset):
+    """List of graphs (networkx graphs, or (R,R) adjacency arrays) -> padded records with
+    `x`, `edge_index`, `adj_dense` (unit diagonal on real nodes), `num_real_nodes`."""
+
+    def __init__(self, graphs, max_nodes: int, feature_type: str = "id") -> None:
+        if feature_type not in ("id", "deg"):
+            raise ValueError(f"Unknown feature_type: {feature_type}")
+        self.graphs = graphs
+        self.max_nodes = max_nodes
+        self.feature_type = feature_type
+
+    def __len__(self) -> int:
+        return len(self.graphs)
+
+    def __getitem__(self, idx) -> GraphData:
+        g = self.graphs[idx]
+        if isinstance(g, np.ndarray):
+            return graph_from_adjacency(g, self.max_nodes, self.feature_type)
+        return graph_from_networkx(g, self.max_nodes, self.feature_type)
+
+    def dense(self) -> DenseGraphBatch:
+        """The whole dataset as one padded batch on the host."""
+        return collate([self[i] for i in range(len(self))], self.max_nodes)
+
+
+def _num_nodes(g) -> int:
+    return g.shape[0] if isinstance(g, np.ndarray) else g.number_of_nodes()
+
+
+def load_tu_dataset(name: str, root: str = "/tmp/TUD"):
+    """TU-format reader for a dataset already on disk (`root/name/raw/name_A.txt`,
+    `name_graph_indicator.txt`); nothing is downloaded."""
+    raw = Path(root) / name / "raw"
+    a_file, gi_file = raw / f"{name}_A.txt", raw / f"{name}_graph_indicator.txt"
+    if not a_file.exists() or not gi_file.exists():
+        raise FileNotFoundError(
+            f"{name}: {a_file} / {gi_file} not found; place the TU dataset files there "
+            "(no network download is attempted) or use --dataset synthetic-enzymes")
+    gi = np.loadtxt(gi_file, dtype=np.int64)
+    edges = np.loadtxt(a_file, delimiter=",", dtype=np.int64)
+    n_graphs = int(gi.max())
+    first = np.searchsorted(gi, np.arange(1, n_graphs + 1))
+    sizes = np.bincount(gi, minlength=n_graphs + 1)[1:]
+    adjs = [np.zeros((s, s), np.float32) for s in sizes]
+    for u, v in edges:
+        g = gi[u - 1] - 1
+        adjs[g][u - 1 - first[g], v - 1 - first[g]] = 1.0
+    return [np.maximum(a, a.T) for a in adjs]
+
+
+def build_graph_list(dataset: str, max_nodes: int | None, n_synthetic: int = 600):
+    if dataset == "grid":
+        import networkx as nx
+        graphs = [nx.grid_2d_graph(i, j) for i, j in itertools.product(range(2, 4), repeat=2)]
+    elif dataset == "enzymes":
+        graphs = load_tu_dataset("ENZYMES")
+    elif dataset in ("synthetic-dense", "synthetic-enzymes"):
+        kind = dataset.split("-")[1]
+        graphs = synthetic_adjacencies(kind, n_synthetic, max_nodes or (32 if kind == "dense" else 126),
+                                       seed=0)
+    else:
+        raise ValueError("dataset must be 'grid', 'enzymes', 'synthetic-dense' or 'synthetic-enzymes'")
+    if max_nodes is None:
+        max_nodes = max(_num_nodes(g) for g in graphs)
+    graphs = [g for g in graphs if _num_nodes(g) <= max_nodes]
+    return graphs, max_nodes
+
+
+def shard_indices(n: int, world: int, rank: int, shuffle: bool, epoch: int, seed: int = 0):
+    """Sample order of one rank: same rule as torch's DistributedSampler (pad by
+    repetition to a multiple of world, then take rank::world)."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    total = (n + world - 1) // world * world
+    if total > n:
+        idx += (idx * ((total - n + n - 1) // n))[: total - n]
+    return idx[rank:total:world]
+
+
+# --------------------------------------------------------------------------- the step
+class TrainStep:
+    """forward + backward + gradient all-reduce + clip + Adam, all on flat buffers.
+    loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
+
+    def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
+                 world: int = 1, group=None, sync_bn_buffers: bool = True) -> None:
+        self.model = model
+        self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
+        self.world, self.group = world, group
+        self.sync_bn_buffers = sync_bn_buffers
+        flat = model.flat_parameters()
+        self.grads = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.t = 0
+
+    def __call__(self, batch: DenseGraphBatch, beta: float, lr_scale: float,
+                 eps: torch.Tensor | None = None) -> torch.Tensor:
+        """One optimisation step; returns a copy of [rec, kl, max_logit, logvar_max] (device).
+        `eps` (B, z_dim) overrides the reparameterisation noise (tests)."""
+        model = self.model
+        if self.world > 1 and self.sync_bn_buffers:
+            # DDP's broadcast_buffers: every forward starts from rank 0's running statistics
+            dist.broadcast(model.bn_state(), src=0, group=self.group)
+        eng = model._engine_for(batch)
+        if eps is None:
+            eps = torch.randn(batch.num_graphs, model.z_dim, dtype=torch.float32, device=batch.device)
+        out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
+                           model._pos_weight_dev(), True).clone()
+        eng.backward(model.flat_parameters(), model._pos_weight_dev(), self.grads, 1.0, beta)
+        if self.world > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+        self.t += 1
+        eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
+                      self.lr * lr_scale, weight_decay=self.weight_decay, clip_max=self.clip_max,
+                      grad_scale=1.0 / self.world, norm_out=self.grad_norm)
+        for bn in (model.bn1, model.bn2):
+            bn.num_batches_tracked += batch.num_graphs
+        return out4
+
+
+class _NoDbg:
+    step = 0
+
+    def log(self, *_, **__):
+        pass
+
+    def next(self):
+        self.step += 1
+
+
+class DebugState(_NoDbg):
+    """Per-step scalars to TensorBoard / W&B when those packages are present."""
+
+    def __init__(self, writer, wandb_run) -> None:
+        self.tb, self.wb = writer, wandb_run
+
+    def log(self, tag, value):
+        if self.tb is not None:
+            self.tb.add_scalar(tag, value, self.step)
+        if self.wb is not None:
+            self.wb.log({tag: value, "step": self.step})
+
+
+def finite_or_raise(t, name):
+    if not torch.isfinite(t).all():
+        raise FloatingPointError(f"{name} contains inf / nan")
+
+
+def _optional_loggers(args, rank: int):
+    tb = wb = None
+    if rank != 0:
+        return tb, wb
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        tb = SummaryWriter(Path(args.log_dir, "tb"))
+    except Exception:
+        tb = None
+    if getattr(args, "use_wandb", False) and os.getenv("WANDB_DISABLED", "0") not in ("true", "1"):
+        try:
+            import wandb
+            wb = wandb.init(project="graphvae", name=args.run_name or f"{args.dataset}-ddp",
+                            dir=args.log_dir, config=vars(args))
+        except Exception:
+            wb = None
+    return tb, wb
+
+
+# --------------------------------------------------------------------------- worker
+def _ddp_worker(rank: int, world: int, args) -> None:
+    _set_seed()
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    use_gpu = torch.cuda.is_available()
+    if not use_gpu:
+        raise RuntimeError("graphvae.train.train_ddp needs a GPU (the HIP step has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    spawned = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        spawned = True
+
+    # graphs: every rank builds the same list; rank 0's shuffle order is broadcast
+    graphs, max_nodes = build_graph_list(args.dataset, args.max_nodes)
+    order = list(range(len(graphs)))
+    if rank == 0:
+        random.shuffle(order)
+    if world > 1:
+        box = [order]
+        dist.broadcast_object_list(box, src=0)
+        order = box[0]
+    graphs = [graphs[i] for i in order]
+    split = int(0.9 * len(graphs))
+    g_train, g_val = graphs[:split], graphs[split:]
+
+    ds_tr = GraphDataset(g_train, max_nodes=max_nodes, feature_type=args.feature_type)
+    ds_va = GraphDataset(g_val, max_nodes=max_nodes, feature_type=args.feature_type)
+    dense_tr = ds_tr.dense()
+    n_tr, n_va = len(ds_tr), len(ds_va)
+    dl_tr = DenseLoader(dense_tr, args.batch_size,
+                        lambda ep: shard_indices(n_tr, world, rank, True, ep), device)
+    dl_va = DenseLoader(ds_va.dense(), args.batch_size,
+                        lambda ep: shard_indices(n_va, world, rank, False, ep), device) if n_va else []
+
+    model = GraphVAE(in_dim=args.in_dim, hid_dim=args.hid_dim, z_dim=args.z_dim, max_nodes=max_nodes,
+                     pool=args.pool, matching=getattr(args, "matching", "auto")).to(device)
+    # rho over the full training set, identical on every rank (same data, same arithmetic)
+    model.precompute_dataset_rho([dense_tr])
+    if world > 1:
+        dist.broadcast(model.flat_parameters(), src=0)
+        dist.broadcast(model.bn_state(), src=0)
+        dist.barrier()
+
+    step_fn = TrainStep(model, args.lr, args.weight_decay, args.clip_max, world)
+    tb, wb = _optional_loggers(args, rank)
+    dbg = DebugState(tb, wb) if (args.debug and rank == 0) else _NoDbg()
+
+    steps_per_epoch = len(dl_tr)
+    anneal_steps = max(1, args.warm_epochs * steps_per_epoch)
+    global_step = 0
+    acc = torch.zeros(1, dtype=torch.float64, device=device)
+
+    for ep in range(args.epochs):
+        dl_tr.set_epoch(ep)
+        model.train()
+        acc.zero_()
+        for batch in dl_tr:
+            frac = min(1.0, global_step / anneal_steps)
+            beta = args.beta0 + (args.beta_final - args.beta0) * frac
+            out4 = step_fn(batch, beta, frac)
+            acc += (out4[0] + beta * out4[1]).double()      # stays on the device: no per-step sync
+            if args.debug and rank == 0:
+                o = out4.tolist()
+                dbg.log("train/rec", o[0])
+                dbg.log("train/kl", o[1])
+                dbg.log("train/loss", o[0] + beta * o[1])
+                dbg.log("debug/max_logit", o[2])
+                dbg.log("debug/logvar_max", o[3])
+                if dbg.step % 10 == 0:
+                    dbg.log("debug/param_norm", model.flat_parameters().norm().item())
+                    dbg.log("debug/grad_norm", step_fn.grad_norm.item())
+            dbg.next()
+            global_step += 1
+        tot_tr = acc.clone()
+        if world > 1:
+            dist.all_reduce(tot_tr, op=dist.ReduceOp.SUM)
+        mean_tr = tot_tr.item() / max(1, len(dl_tr)) / world
+
+        model.eval()
+        acc.zero_()
+        with torch.no_grad():
+            for batch in dl_va:
+                logs = model(batch)
+                acc += (logs["rec"] + args.beta_final * logs["kl"]).double()
+        tot_va = acc.clone()
+        if world > 1:
+            dist.all_reduce(tot_va, op=dist.ReduceOp.SUM)
+        mean_va = tot_va.item() / max(1, len(dl_va)) / world
+
+        if rank == 0:
+            print(f"Ep {ep:03d} | train {mean_tr:.4f} | val {mean_va:.4f}", flush=True)
+            if tb is not None:
+                tb.add_scalars("loss", {"train": mean_tr, "val": mean_va}, ep)
+            if wb is not None:
+                wb.log({"loss/train": mean_tr, "loss/val": mean_va, "epoch": ep})
+
+    if rank == 0:
+        ckpt = Path(args.log_dir, "graphvae_ddp.pt")
+        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, ckpt)
+        print("saved", ckpt)
+        if tb is not None:
+            tb.close()
+        if wb is not None:
+            wb.finish()
+    if spawned:
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- train(cfg)
+_DEFAULTS = dict(
+    dataset="grid", feature_type="deg", lr=1e-4, epochs=200, max_nodes=None, log_dir="runs",
+    use_wandb=True, run_name=None, batch_size=64, weight_decay=1e-4, beta0=0.0, beta_final=0.5,
+    warm_epochs=40, clip_max=5.0, hid_dim=128, z_dim=64, pool="sum", debug=False, matching="auto",
+)
+
+
+def train(cfg) -> None:
+    if isinstance(cfg, dict):
+        cfg = SimpleNamespace(**cfg.get("trainer", cfg))
+    for k, v in _DEFAULTS.items():
+        if getattr(cfg, k, None) is None and k not in ("max_nodes", "run_name"):
+            setattr(cfg, k, v)
+        elif not hasattr(cfg, k):
+            setattr(cfg, k, v)
+    for key in ("lr", "weight_decay", "beta0", "beta_final", "clip_max"):
+        val = getattr(cfg, key)
+        if isinstance(val, str):
+            try:
+                setattr(cfg, key, float(val))
+            except ValueError:
+                raise ValueError(f"{key} should be numeric, got {val!r}")
+
+    if cfg.log_dir in ("runs", "./runs"):
+        cfg.log_dir = str(Path("runs") / datetime.now().strftime("%Y%m%d_%H%M%S"))
+    Path(cfg.log_dir).mkdir(parents=True, exist_ok=True)
+
+    graphs, max_nodes_auto = build_graph_list(cfg.dataset, cfg.max_nodes)
+    probe = GraphDataset([graphs[0]], feature_type=cfg.feature_type,
+                         max_nodes=cfg.max_nodes or max_nodes_auto)
+    cfg.in_dim = int(probe[0].x.size(-1))
+
+    if os.environ.get("RANK", "0") == "0":
+        with open(Path(cfg.log_dir) / "params.yaml", "w") as f:
+            yaml.safe_dump(vars(cfg), f, sort_keys=False)
+            print("saved params to", f.name)
+
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world > 1 and not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
+            dist.init_process_group("nccl")
+            try:
+                _ddp_worker(int(os.environ["RANK"]), world, cfg)
+            finally:
+                dist.destroy_process_group()
+        else:
+            _ddp_worker(int(os.environ["RANK"]), world, cfg)
+    else:
+        world = torch.cuda.device_count()
+        if world <= 1:
+            _ddp_worker(0, 1, cfg)
+        else:
+            torch.multiprocessing.spawn(_ddp_worker, nprocs=world, args=(world, cfg))
+
+
+def main(argv=None) -> None:
+    pa = argparse.ArgumentParser(description="GraphVAE data-parallel training (MI355X HIP step)")
+    pa.add_argument("--dataset", choices=["grid", "enzymes", "synthetic-dense", "synthetic-enzymes"],
+                    default=None)
+    pa.add_argument("--feature_type", choices=["id", "deg"], default=None)
+    pa.add_argument("--epochs", type=int, default=None)
+    pa.add_argument("--lr", type=float, default=None)
+    pa.add_argument("--batch_size", type=int, default=None)
+    pa.add_argument("--max_nodes", type=int, default=None)
+    pa.add_argument("--matching", choices=["auto", "stream", "fused"], default=None,
+                    help="MPM kernel: stream the materialised similarity tensor, or the fused S-free form")
+    pa.add_argument("--log_dir", default="runs")
+    pa.add_argument("--config", help="YAML config with a 'trainer:' section")
+    pa.add_argument("--no_wandb", action="store_true", help="disable Weights & Biases logging")
+    pa.add_argument("--run_name", help="custom W&B run name")
+    pa.add_argument("--debug", action="store_true", help="per-step scalars to TB / W&B")
+    args = pa.parse_args(argv)
+    args.use_wandb = not args.no_wandb
+    ycfg = {}
+    if args.config:
+        with open(args.config) as f:
+            ycfg = yaml.safe_load(f).get("trainer", {})
+    cli = {k: v for k, v in vars(args).items() if k not in ("config", "no_wandb") and v is not None}
+    if not args.debug:
+        cli.pop("debug", None)          # a store_true default must not override the YAML value
+    if not args.no_wandb:
+        cli.pop("use_wandb", None)
+    train(SimpleNamespace(**{**ycfg, **cli}))
+
+
+if __name__ == "__main__":
+    main()

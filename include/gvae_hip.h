@@ -175,7 +175,10 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
 
 /* Pointer into the workspace for inspection by tests: which = 0 edge logits (B,U),
  * 1 node logits (B,N), 2 P (B,N,N), 3 X (B,N,N), 4 mu, 5 logvar (pre-clamp) (B,Z),
- * 6 rec_i, 7 kl_i (B), 8 assignment status (B, int32). */
+ * 6 rec_i, 7 kl_i (B), 8 assignment status (B, int32), 9 Y1, 10 H1, 11 Y2, 12 H2 (B,N,H:
+ * aggregated pre-BatchNorm values without bias / post-ReLU activations of the two GCN
+ * layers), 13 pooled vector (B,H), 14 normalised adjacency (B,N,N), 15 dY of layer 1 after
+ * a backward (B,N,H), 16 d(pooled vector) (B,H). */
 int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which, float **out_ptr,
                          int64_t *out_count);
 

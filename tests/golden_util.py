@@ -62,7 +62,7 @@ def truth64(G):
 
 def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e-5):
     """Each gradient tensor within `tol` relative (to its largest entry) of the
-    reference's, plus, when `truth` (float64 recomputation) is given, twice the
+    reference's, plus, when `truth` (float64 recomputation) is given, four times the
     reference's own distance from it -- a result cannot be asked to sit closer to the
     fp32 reference than that reference sits to the exact value.  The two GCN biases feed
     straight into a training-mode BatchNorm, which cancels any per-column constant: their
@@ -76,7 +76,7 @@ def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e
         if name in ZERO_GRAD_PARAMS:
             assert np.abs(g).max() <= 20 * tol * gmax and np.abs(r).max() <= 20 * tol * gmax, name
             continue
-        slack = 2.0 * float(np.abs(r - truth[name]).max()) if truth is not None else 0.0
+        slack = 4.0 * float(np.abs(r - truth[name]).max()) if truth is not None else 0.0
         err = float(np.abs(g - r).max())
         assert err <= tol * max(np.abs(r).max(), 1e-30) + slack, (name, err, float(np.abs(r).max()), slack)
 
