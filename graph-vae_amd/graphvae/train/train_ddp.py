@@ -138,8 +138,11 @@ class TrainStep:
     loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
 
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
-                 world: int = 1, group=None, sync_bn_buffers: bool = True) -> None:
+                 world: int = 1, group=None, sync_bn_buffers: bool = True, engine=None) -> None:
+        """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
+        model's HIP engine (tests inject a CPU checker to exercise the collective pattern)."""
         self.model = model
+        self._engine = engine
         self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
         self.world, self.group = world, group
         self.sync_bn_buffers = sync_bn_buffers
@@ -158,7 +161,7 @@ class TrainStep:
         if self.world > 1 and self.sync_bn_buffers:
             # DDP's broadcast_buffers: every forward starts from rank 0's running statistics
             dist.broadcast(model.bn_state(), src=0, group=self.group)
-        eng = model._engine_for(batch)
+        eng = self._engine if self._engine is not None else model._engine_for(batch)
         if eps is None:
             eps = torch.randn(batch.num_graphs, model.z_dim, dtype=torch.float32, device=batch.device)
         out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
