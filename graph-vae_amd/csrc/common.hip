@@ -28,13 +28,20 @@ struct EventPair {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-static std::vector<EventPair> g_events;
+static std::vector<EventPair> g_events;   // pairs recorded since the last reset
+static std::vector<EventPair> g_pool;     // created events kept for reuse (creation is slow)
 
 ProfileScope::ProfileScope(int fam, hipStream_t s) : family(fam), stream(s), slot(-1) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   EventPair p{fam, nullptr, nullptr};
-  if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) return;
+  if (!g_pool.empty()) {
+    p = g_pool.back();
+    p.family = fam;
+    g_pool.pop_back();
+  } else if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) {
+    return;
+  }
   hipEventRecord(p.start, s);
   g_events.push_back(p);
   slot = (int)g_events.size() - 1;
@@ -62,10 +69,7 @@ int gvae_profile_enable(int on) {
 
 int gvae_profile_reset(void) {
   std::lock_guard<std::mutex> lk(gvae::g_prof_mu);
-  for (auto &p : gvae::g_events) {
-    hipEventDestroy(p.start);
-    hipEventDestroy(p.stop);
-  }
+  for (auto &p : gvae::g_events) gvae::g_pool.push_back(p);
   gvae::g_events.clear();
   return GVAE_OK;
 }

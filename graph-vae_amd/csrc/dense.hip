@@ -234,27 +234,41 @@ int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, co
   return check_launch("bn_relu_fwd");
 }
 
-// B sequential momentum updates, one per graph in batch order (the reference
-// applies BatchNorm graph by graph, model.py:295-296).
-__global__ void bn_running_update_kernel(const float *__restrict__ mean,
-                                         const float *__restrict__ var_unb, int B, int H,
-                                         float momentum, float *__restrict__ run_mean,
-                                         float *__restrict__ run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
-  float rm = run_mean[c], rv = run_var[c];
-  for (int g = 0; g < B; ++g) {
-    rm = momentum * mean[(int64_t)g * H + c] + (1.0f - momentum) * rm;
-    rv = momentum * var_unb[(int64_t)g * H + c] + (1.0f - momentum) * rv;
+// The reference applies BatchNorm graph by graph (model.py:295-296), i.e. B sequential
+// momentum updates r <- (1-m) r + m s_g in batch order.  Their closed form
+//   r_B = (1-m)^B r_0 + sum_g m (1-m)^(B-1-g) s_g
+// is evaluated here with one work-group per column (sum in double, one rounding).
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float *__restrict__ mean,
+                                                                const float *__restrict__ var_unb,
+                                                                int B, int H, float momentum,
+                                                                float *__restrict__ run_mean,
+                                                                float *__restrict__ run_var) {
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double keep = 1.0 - (double)momentum;
+  double sm = 0.0, sv = 0.0;
+  for (int g = tid; g < B; g += 256) {
+    const double w = (double)momentum * pow(keep, (double)(B - 1 - g));
+    sm += w * (double)mean[(int64_t)g * H + c];
+    sv += w * (double)var_unb[(int64_t)g * H + c];
   }
-  run_mean[c] = rm;
-  run_var[c] = rv;
+  for (int off = 32; off > 0; off >>= 1) {
+    sm += __shfl_xor(sm, off, 64);
+    sv += __shfl_xor(sv, off, 64);
+  }
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = sm; sh[1][tid >> 6] = sv; }
+  __syncthreads();
+  if (tid == 0) {
+    const double k0 = pow(keep, (double)B);
+    run_mean[c] = (float)(k0 * (double)run_mean[c] + ((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])));
+    run_var[c] = (float)(k0 * (double)run_var[c] + ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])));
+  }
 }
 
 int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
                              float *run_mean, float *run_var, hipStream_t s) {
-  hipLaunchKernelGGL(bn_running_update_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, s, mean, var_unb,
-                     B, H, momentum, run_mean, run_var);
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(H), dim3(256), 0, s, mean, var_unb, B, H,
+                     momentum, run_mean, run_var);
   return check_launch("bn_running_update");
 }
 
@@ -322,21 +336,33 @@ int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, con
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ M, int rows, int cols,
                                                      int64_t ld, float *__restrict__ out,
                                                      int accumulate) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-  float s = 0.0f;
-  if (c < cols) for (int r = rl; r < rows; r += 4) s += M[(int64_t)r * ld + c];
-  sh[rl][cl] = s;
+  // 16 columns x 16 row lanes per work-group; each lane keeps 4 loads in flight
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+      s0 += M[(int64_t)r * ld + c];
+      s1 += M[(int64_t)(r + 16) * ld + c];
+      s2 += M[(int64_t)(r + 32) * ld + c];
+      s3 += M[(int64_t)(r + 48) * ld + c];
+    }
+    for (; r < rows; r += 16) s0 += M[(int64_t)r * ld + c];
+  }
+  sh[rl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rl == 0 && c < cols) {
-    const float t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
     out[c] = accumulate ? out[c] + t : t;
   }
 }
 
 int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
                   hipStream_t s) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, M, rows, cols, ld, out,
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 16)), dim3(256), 0, s, M, rows, cols, ld, out,
                      accumulate);
   return check_launch("colsum");
 }

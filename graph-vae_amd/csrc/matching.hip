@@ -220,47 +220,6 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
   }
 }
 
-__global__ void mpm_stream_iter_kernel(const float *__restrict__ S,
-                                       const int64_t *__restrict__ S_off,
-                                       const int32_t *__restrict__ Rarr,
-                                       const float *__restrict__ X, int ldx, int64_t strideX,
-                                       float *__restrict__ Xnew, int64_t strideXnew,
-                                       const int32_t *__restrict__ flags) {
-  extern __shared__ float lds[];
-  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int R = Rarr[g];
-  if (i >= R || flags[g] != 0) return;
-  const int R2 = R * R;
-  float *Xs = lds;            // R*R
-  float *T = lds + R2;        // R*R
-  float *nsrow = T + R2;      // R
-  const float *Xg = X + g * strideX;
-  for (int e = tid; e < R2; e += nt) {
-    const int r = e / R, c = e - r * R;
-    Xs[e] = Xg[(int64_t)r * ldx + c];
-  }
-  __syncthreads();
-  const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
-  if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
-  else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
-  else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
-  __syncthreads();
-  float *Xn = Xnew + g * strideXnew;
-  for (int p = tid; p < R; p += nt) {
-    const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
-    Xn[i * R + p] = Xs[i * R + p] * nsrow[p] + et;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// MPM normalise + convergence test, one work-group per graph.
-//   nrm = ||Xnew||_2 (canonical order);  X = Xnew / nrm;  converged if
-//   max|X - Xprev| < tol (fp32 compare) and early_stop.
-// The norm's eight fused chains are inherently serial; Xnew is staged through LDS
-// in tiles so the chain threads read it at LDS latency.
-// ---------------------------------------------------------------------------
-#define NORM_TILE 4096
-
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
 __device__ __forceinline__ float norm_chain(const float *x, int n, int lane, float acc) {
   int d = 0;
@@ -290,45 +249,86 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
   return sqrtf(s);
 }
 
-__global__ __launch_bounds__(256) void mpm_stream_norm_kernel(
-    const float *__restrict__ Xnew, int64_t strideXnew, const int32_t *__restrict__ Rarr,
-    float *__restrict__ X, int ldx, int64_t strideX, float tol, int early_stop,
-    int32_t *__restrict__ flags, int32_t *__restrict__ iters_done) {
-  __shared__ float tile[NORM_TILE];
-  __shared__ float red[8];
+// One launch = one MPM iteration for every unconverged graph.  The R work-groups of a
+// graph each produce one row of Xnew; the one that arrives last (per-graph arrival counter:
+// rows stored write-through and drained before the producer's ticket, agent-scope acquire by
+// the last arriver before it reads the rows) also normalises:
+//   nrm = ||Xnew||_2 (canonical order);  X = Xnew / nrm;  converged if max|X - Xprev| < tol
+// so an iteration is a single kernel and no work-group ever waits for another.
+__global__ void mpm_stream_iter_kernel(const float *__restrict__ S,
+                                       const int64_t *__restrict__ S_off,
+                                       const int32_t *__restrict__ Rarr, float *__restrict__ X,
+                                       int ldx, int64_t strideX, float *__restrict__ Xnew,
+                                       int64_t strideXnew, float tol, int early_stop,
+                                       int32_t *__restrict__ flags, int32_t *__restrict__ arrive,
+                                       int32_t *__restrict__ iters_done) {
+  extern __shared__ float lds[];
+  __shared__ float red[16];
   __shared__ float s_nrm;
-  const int g = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_last;
+  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int R = Rarr[g];
-  if (R <= 0 || flags[g] != 0) return;
+  if (i >= R || flags[g] != 0) return;
   const int R2 = R * R;
-  const float *Xn = Xnew + g * strideXnew;
+  float *Xs = lds;            // R*R
+  float *T = lds + R2;        // R*R
+  float *nsrow = T + R2;      // R
   float *Xg = X + g * strideX;
-  const int n8 = R2 & ~7;
-  float acc = 0.f;
-  for (int base = 0; base < R2; base += NORM_TILE) {
-    const int n = min(NORM_TILE, R2 - base);
-    __syncthreads();
-    for (int e = tid; e < n; e += 256) tile[e] = Xn[base + e];
-    __syncthreads();
-    if (tid < 64) {
-      const int nfull = min(n, n8 - base) > 0 ? min(n, n8 - base) : 0;
-      if (tid < 8) acc = norm_chain(tile, nfull, tid, acc);
-      if (base + n >= R2) {
-        const float nrm = norm_finish(acc, tile + nfull, n - nfull);
-        if (tid == 0) s_nrm = nrm;
-      }
+  for (int e = tid; e < R2; e += nt) {
+    const int r = e / R, c = e - r * R;
+    Xs[e] = Xg[(int64_t)r * ldx + c];
+  }
+  __syncthreads();
+  const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
+  if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
+  else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
+  else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
+  __syncthreads();
+  float *Xn = Xnew + g * strideXnew;
+  for (int p = tid; p < R; p += nt) {
+    const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
+    // write-through (agent-scope) store: the row is handed to another work-group below, and a
+    // write-through payload needs no release fence (an L2 write-back per work-group is far
+    // more expensive than these R small stores)
+    __hip_atomic_store(&Xn[i * R + p], Xs[i * R + p] * nsrow[p] + et, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // publish this row: every storing wave drains its stores, then one lane takes a ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int ticket = __hip_atomic_fetch_add(&arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (ticket == R - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      arrive[g] = 0;  // ready for the next launch
     }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- last arriver: normalise the graph
+  for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
+  __syncthreads();
+  const int n8 = R2 & ~7;
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8) acc = norm_chain(T, n8, tid, acc);
+    const float nrm = norm_finish(acc, T + n8, R2 - n8);
+    if (tid == 0) s_nrm = nrm;
   }
   __syncthreads();
   const float nrm = s_nrm;
   float dmax = 0.f;
   bool isnan_any = false;
-  for (int e = tid; e < R2; e += 256) {
-    const int r = e / R, c = e - r * R;
-    const float v = Xn[e] / nrm;
-    const float d = fabsf(v - Xg[(int64_t)r * ldx + c]);
+  for (int e = tid; e < R2; e += nt) {
+    const float v = T[e] / nrm;
+    const float d = fabsf(v - Xs[e]);
     isnan_any |= (d != d);
     dmax = fmaxf(dmax, d);
+    const int r = e / R, c = e - r * R;
     Xg[(int64_t)r * ldx + c] = v;
   }
   if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
@@ -336,9 +336,10 @@ __global__ __launch_bounds__(256) void mpm_stream_norm_kernel(
   if ((tid & 63) == 0) red[tid >> 6] = dmax;
   __syncthreads();
   if (tid == 0) {
-    dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float d = red[0];
+    for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
     iters_done[g] += 1;
-    if (early_stop && dmax < tol) flags[g] = 1;
+    if (early_stop && d < tol) flags[g] = 1;
   }
 }
 
@@ -448,11 +449,12 @@ __global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__res
   if (tid == 0) iters_done[g] = done;
 }
 
-__global__ void zero_i32_kernel(int32_t *a, int32_t *b, int n) {
+__global__ void zero_i32_kernel(int32_t *a, int32_t *b, int32_t *c, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) {
     a[t] = 0;
     b[t] = 0;
+    c[t] = 0;
   }
 }
 
@@ -494,10 +496,11 @@ int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const i
 }
 
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
-  // Xnew (n_graphs * ldx * ldx floats) + flags (n_graphs int32), 256-byte aligned parts
+  // Xnew (n_graphs * ldx * ldx floats) + flags + arrival counters (n_graphs int32 each),
+  // 256-byte aligned parts
   int64_t xb = ((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL;
   int64_t fb = ((int64_t)n_graphs * 4 + 255) & ~255LL;
-  return xb + fb;
+  return xb + 2 * fb;
 }
 
 int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R, int n_graphs,
@@ -517,7 +520,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R
   float *Xnew = (float *)d_ws;
   const int64_t strideXnew = (int64_t)ldx * ldx;
   int32_t *flags = (int32_t *)((char *)d_ws + (((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL));
-  hipLaunchKernelGGL(zero_i32_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, flags,
+  int32_t *arrive = (int32_t *)((char *)flags + (((int64_t)n_graphs * 4 + 255) & ~255LL));
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, flags, arrive,
                      d_iters_done, n_graphs);
   const int nt = r_max > 64 ? 1024 : 256;
   if (lds > 48 * 1024) {
@@ -527,16 +531,10 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R
                  lds, hipGetErrorString(e));
   }
   for (int it = 0; it < iters; ++it) {
-    {
-      ProfileScope ps(F_MPM_ITER, s);
-      hipLaunchKernelGGL(mpm_stream_iter_kernel, dim3(r_max, n_graphs), dim3(nt), lds, s, d_S,
-                         d_S_off, d_R, d_X, ldx, strideX, Xnew, strideXnew, flags);
-    }
-    {
-      ProfileScope ps(F_MPM_NORM, s);
-      hipLaunchKernelGGL(mpm_stream_norm_kernel, dim3(n_graphs), dim3(256), 0, s, Xnew, strideXnew,
-                         d_R, d_X, ldx, strideX, tol, early_stop, flags, d_iters_done);
-    }
+    ProfileScope ps(F_MPM_ITER, s);
+    hipLaunchKernelGGL(mpm_stream_iter_kernel, dim3(r_max, n_graphs), dim3(nt), lds, s, d_S, d_S_off,
+                       d_R, d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, flags, arrive,
+                       d_iters_done);
   }
   return check_launch("mpm_stream");
 }
