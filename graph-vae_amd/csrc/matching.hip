@@ -249,98 +249,211 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
   return sqrtf(s);
 }
 
-// One launch = one MPM iteration for every unconverged graph.  The R work-groups of a
-// graph each produce one row of Xnew; the one that arrives last (per-graph arrival counter:
-// rows stored write-through and drained before the producer's ticket, agent-scope acquire by
-// the last arriver before it reads the rows) also normalises:
-//   nrm = ||Xnew||_2 (canonical order);  X = Xnew / nrm;  converged if max|X - Xprev| < tol
-// so an iteration is a single kernel and no work-group ever waits for another.
-__global__ void mpm_stream_iter_kernel(const float *__restrict__ S,
-                                       const int64_t *__restrict__ S_off,
-                                       const int32_t *__restrict__ Rarr, float *__restrict__ X,
-                                       int ldx, int64_t strideX, float *__restrict__ Xnew,
-                                       int64_t strideXnew, float tol, int early_stop,
-                                       int32_t *__restrict__ flags, int32_t *__restrict__ arrive,
-                                       int32_t *__restrict__ iters_done) {
+// The whole MPM of a batch in ONE launch, driven by a work queue.
+//   * work item = (graph g, row i) of one iteration: stream the slab S[g][i,:,:,:] once and
+//     produce row i of Xnew[g];
+//   * the R producers of a graph hand their rows to whichever of them arrives last (per-graph
+//     arrival counter: rows stored write-through and drained before the producer's ticket,
+//     agent-scope acquire by the last arriver before it reads them).  That work-group
+//     normalises (nrm = ||Xnew||_2 in canonical order, X = Xnew / nrm) and, unless the graph
+//     has converged (max|X - Xprev| < tol) or used up its iterations, pushes the graph's R
+//     items of the next iteration into the queue;
+//   * the queue is a ring of 8-byte {generation, item} granules with a head and a tail ticket
+//     counter.  A consumer draws a ticket and polls ITS OWN slot until the granule of its
+//     generation appears (or until no graph is left), then clears the slot.  At most
+//     sum_g R_g <= capacity items are ever undrawn (a graph's next items are pushed only after
+//     all of its current ones were consumed), so when a producer reaches a slot the ticket one
+//     lap earlier has already been drawn; it only has to wait for that consumer's clear, which
+//     never depends on another work-group.  Every spin is bounded and reports through the
+//     error word instead of hanging.
+// Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
+// everything else instead of costing one under-filled launch per iteration.
+#define MPM_NULL_ITEM 0xFFFFFFFFu
+#define MPM_SPIN_LIMIT (1u << 21)
+
+struct MpmQueue {
+  unsigned long long *slots;  // [cap]
+  int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [96] error
+  int32_t *arrive;            // [n_graphs]
+  unsigned cap;
+};
+#define Q_HEAD(q) ((q).words + 0)
+#define Q_TAIL(q) ((q).words + 32)
+#define Q_REMAIN(q) ((q).words + 64)
+#define Q_ERROR(q) ((q).words + 96)
+
+__global__ void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
+                                  const int32_t *__restrict__ Rarr, int r_max,
+                                  float *__restrict__ X, int ldx, int64_t strideX,
+                                  float *__restrict__ Xnew, int64_t strideXnew, float tol,
+                                  int early_stop, int iters, MpmQueue q,
+                                  int32_t *__restrict__ iters_done) {
   extern __shared__ float lds[];
   __shared__ float red[16];
   __shared__ float s_nrm;
-  __shared__ int s_last;
-  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int R = Rarr[g];
-  if (i >= R || flags[g] != 0) return;
-  const int R2 = R * R;
-  float *Xs = lds;            // R*R
-  float *T = lds + R2;        // R*R
-  float *nsrow = T + R2;      // R
-  float *Xg = X + g * strideX;
-  for (int e = tid; e < R2; e += nt) {
-    const int r = e / R, c = e - r * R;
-    Xs[e] = Xg[(int64_t)r * ldx + c];
-  }
-  __syncthreads();
-  const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
-  if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
-  else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
-  else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
-  __syncthreads();
-  float *Xn = Xnew + g * strideXnew;
-  for (int p = tid; p < R; p += nt) {
-    const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
-    // write-through (agent-scope) store: the row is handed to another work-group below, and a
-    // write-through payload needs no release fence (an L2 write-back per work-group is far
-    // more expensive than these R small stores)
-    __hip_atomic_store(&Xn[i * R + p], Xs[i * R + p] * nsrow[p] + et, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // publish this row: every storing wave drains its stores, then one lane takes a ticket
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const int ticket = __hip_atomic_fetch_add(&arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (ticket == R - 1) ? 1 : 0;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      arrive[g] = 0;  // ready for the next launch
+  __shared__ int s_item, s_last, s_cont, s_base;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (;;) {
+    // ---- draw a ticket and wait for its granule (one lane)
+    if (tid == 0) {
+      const unsigned ticket = (unsigned)__hip_atomic_fetch_add(Q_HEAD(q), 1, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned slot = ticket % q.cap, want = ticket / q.cap + 1u;
+      int got = 0;
+      unsigned item = MPM_NULL_ITEM;
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned long long v =
+            __hip_atomic_load(&q.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == want) {
+          item = (unsigned)v;
+          got = 1;
+          // free the slot for the ticket one lap later
+          __hip_atomic_store(&q.slots[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 3u) == 3u &&
+            __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0)
+          break;                                   // every graph is finished: nothing will come
+        if (spins > MPM_SPIN_LIMIT) {              // never expected; do not hang the device
+          __hip_atomic_store(Q_ERROR(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      // the item's graph state (X, iteration count) was written by another work-group
+      if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_item = got ? (int)item : -2;
     }
-    s_last = last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int item = s_item;
+    if (item == -2) break;
+    if ((unsigned)item != MPM_NULL_ITEM) {
+      const int g = item / r_max, i = item - g * r_max;
+      const int R = Rarr[g];
+      const int R2 = R * R;
+      float *Xs = lds;            // R*R
+      float *T = lds + R2;        // R*R
+      float *nsrow = T + R2;      // R
+      float *Xg = X + g * strideX;
+      for (int e = tid; e < R2; e += nt) {
+        const int r = e / R, c = e - r * R;
+        Xs[e] = Xg[(int64_t)r * ldx + c];
+      }
+      __syncthreads();
+      const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
+      if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
+      else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
+      else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
+      __syncthreads();
+      float *Xn = Xnew + g * strideXnew;
+      for (int p = tid; p < R; p += nt) {
+        const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
+        // write-through store (no release fence needed for a write-through payload)
+        __hip_atomic_store(&Xn[i * R + p], Xs[i * R + p] * nsrow[p] + et, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // publish this row: every storing wave drains its stores, then one lane takes a ticket
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int ticket =
+            __hip_atomic_fetch_add(&q.arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == R - 1) ? 1 : 0;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_last = last;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s_last) {
+        // ---- last arriver: normalise the graph
+        for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
+        __syncthreads();
+        const int n8 = R2 & ~7;
+        if (tid < 64) {
+          float acc = 0.f;
+          if (tid < 8) acc = norm_chain(T, n8, tid, acc);
+          const float nrm = norm_finish(acc, T + n8, R2 - n8);
+          if (tid == 0) s_nrm = nrm;
+        }
+        __syncthreads();
+        const float nrm = s_nrm;
+        float dmax = 0.f;
+        bool isnan_any = false;
+        for (int e = tid; e < R2; e += nt) {
+          const float v = T[e] / nrm;
+          const float d = fabsf(v - Xs[e]);
+          isnan_any |= (d != d);
+          dmax = fmaxf(dmax, d);
+          const int r = e / R, c = e - r * R;
+          // write-through: the next iteration's consumers run on other compute units
+          __hip_atomic_store(&Xg[(int64_t)r * ldx + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = dmax;
+        __syncthreads();
+        if (tid == 0) {
+          float d = red[0];
+          for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
+          const int done = __hip_atomic_load(&iters_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          __hip_atomic_store(&iters_done[g], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&q.arrive[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
+          if (cont)
+            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_cont = cont;
+        }
+        // X, the iteration count and the reset counter are drained before anything is pushed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s_cont) {
+          const unsigned base = (unsigned)s_base;
+          for (int p = tid; p < R; p += nt) {
+            const unsigned t = base + (unsigned)p;
+            const unsigned long long gran =
+                ((unsigned long long)(t / q.cap + 1u) << 32) | (unsigned)(g * r_max + p);
+            unsigned long long *sl = &q.slots[t % q.cap];
+            // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
+            // undrawn), so its consumer is polling this slot and frees it promptly
+            for (unsigned spins = 0;
+                 __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull; ++spins) {
+              if (spins > MPM_SPIN_LIMIT) {
+                __hip_atomic_store(Q_ERROR(q), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(4);
+            }
+            __hip_atomic_store(sl, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else if (tid == 0) {
+          __hip_atomic_fetch_add(Q_REMAIN(q), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __syncthreads();  // s_item and the LDS buffers are free again
   }
-  __syncthreads();
-  if (!s_last) return;
+}
 
-  // ---- last arriver: normalise the graph
-  for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
-  __syncthreads();
-  const int n8 = R2 & ~7;
-  if (tid < 64) {
-    float acc = 0.f;
-    if (tid < 8) acc = norm_chain(T, n8, tid, acc);
-    const float nrm = norm_finish(acc, T + n8, R2 - n8);
-    if (tid == 0) s_nrm = nrm;
+// first generation of the ring: one slot per (graph, i < r_max); rows beyond R are null items
+__global__ void mpm_queue_init_kernel(MpmQueue q, const int32_t *__restrict__ Rarr, int n_graphs,
+                                      int r_max, int32_t *__restrict__ iters_done) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_graphs * r_max) return;
+  const int g = t / r_max, i = t - g * r_max;
+  const int R = Rarr[g];
+  q.slots[t] = (1ull << 32) | (i < R ? (unsigned)t : MPM_NULL_ITEM);
+  if (i == 0) {
+    q.arrive[g] = 0;
+    iters_done[g] = 0;
+    if (R > 0) atomicAdd(Q_REMAIN(q), 1);
   }
-  __syncthreads();
-  const float nrm = s_nrm;
-  float dmax = 0.f;
-  bool isnan_any = false;
-  for (int e = tid; e < R2; e += nt) {
-    const float v = T[e] / nrm;
-    const float d = fabsf(v - Xs[e]);
-    isnan_any |= (d != d);
-    dmax = fmaxf(dmax, d);
-    const int r = e / R, c = e - r * R;
-    Xg[(int64_t)r * ldx + c] = v;
-  }
-  if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
-  for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = dmax;
-  __syncthreads();
-  if (tid == 0) {
-    float d = red[0];
-    for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
-    iters_done[g] += 1;
-    if (early_stop && d < tol) flags[g] = 1;
-  }
+  if (t == 0) *Q_TAIL(q) = n_graphs * r_max;
+}
+
+__global__ void zero_i32_kernel(int32_t *a, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) a[t] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -449,15 +562,6 @@ __global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__res
   if (tid == 0) iters_done[g] = done;
 }
 
-__global__ void zero_i32_kernel(int32_t *a, int32_t *b, int32_t *c, int n) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) {
-    a[t] = 0;
-    b[t] = 0;
-    c[t] = 0;
-  }
-}
-
 }  // namespace gvae
 
 using namespace gvae;
@@ -495,12 +599,12 @@ int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const i
   return check_launch("edge_sim");
 }
 
+static inline int64_t pad256(int64_t b) { return (b + 255) & ~255LL; }
+
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
-  // Xnew (n_graphs * ldx * ldx floats) + flags + arrival counters (n_graphs int32 each),
-  // 256-byte aligned parts
-  int64_t xb = ((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL;
-  int64_t fb = ((int64_t)n_graphs * 4 + 255) & ~255LL;
-  return xb + 2 * fb;
+  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (n_graphs*ldx granules) | arrive
+  return pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 + pad256(8LL * n_graphs * ldx) +
+         pad256(4LL * n_graphs);
 }
 
 int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R, int n_graphs,
@@ -511,30 +615,48 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "mpm_stream: bad sizes (n_graphs=%d r_max=%d ldx=%d iters=%d)", n_graphs, r_max, ldx,
                iters);
-  GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "mpm_stream: more than 65535 graphs per call");
+  GVAE_REQUIRE((int64_t)n_graphs * r_max < (1LL << 30), GVAE_ELIMIT, "mpm_stream: too many graphs");
   const size_t lds = sizeof(float) * (2 * (size_t)r_max * r_max + r_max);
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
-  float *Xnew = (float *)d_ws;
+  if (iters == 0) {
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, d_iters_done,
+                       n_graphs);
+    return check_launch("mpm_stream");
+  }
+  char *w = (char *)d_ws;
+  float *Xnew = (float *)w;
+  w += pad256((int64_t)n_graphs * ldx * ldx * 4);
+  MpmQueue q;
+  q.words = (int32_t *)w;
+  w += 512;
+  q.slots = (unsigned long long *)w;
+  w += pad256(8LL * n_graphs * ldx);
+  q.arrive = (int32_t *)w;
+  const int n_items = n_graphs * r_max;
+  q.cap = (unsigned)n_items;
   const int64_t strideXnew = (int64_t)ldx * ldx;
-  int32_t *flags = (int32_t *)((char *)d_ws + (((int64_t)n_graphs * ldx * ldx * 4 + 255) & ~255LL));
-  int32_t *arrive = (int32_t *)((char *)flags + (((int64_t)n_graphs * 4 + 255) & ~255LL));
-  hipLaunchKernelGGL(zero_i32_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, flags, arrive,
-                     d_iters_done, n_graphs);
+  GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess, GVAE_ELAUNCH,
+               "mpm_stream: memset failed");
+  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(ceil_div(n_items, 256)), dim3(256), 0, s, q, d_R,
+                     n_graphs, r_max, d_iters_done);
   const int nt = r_max > 64 ? 1024 : 256;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_iter_kernel,
+    hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_stream: cannot reserve %zu bytes of LDS: %s",
                  lds, hipGetErrorString(e));
   }
-  for (int it = 0; it < iters; ++it) {
+  // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
+  // others leave, which only happens once every graph is finished, and then leave at once
+  const int max_blocks = nt == 256 ? 2048 : 512;
+  const int blocks = n_items < max_blocks ? n_items : max_blocks;
+  {
     ProfileScope ps(F_MPM_ITER, s);
-    hipLaunchKernelGGL(mpm_stream_iter_kernel, dim3(r_max, n_graphs), dim3(nt), lds, s, d_S, d_S_off,
-                       d_R, d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, flags, arrive,
-                       d_iters_done);
+    hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
+                       d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, iters, q, d_iters_done);
   }
   return check_launch("mpm_stream");
 }
