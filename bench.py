@@ -196,9 +196,22 @@ def main():
             else:
                 alg_bytes = float(np.sum(4.0 * r ** 4 + 12.0 * r ** 2)) * args.mpm_iters
             achieved = alg_bytes / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else 0.0
-            roof = {"kernel": "mpm_stream_iter_kernel", "bound": "hbm", "achieved": achieved,
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as gfx950 needs,
+            # + WRITE_SIZE), measured with rocprofv3 on this workload's kernel and stored per
+            # executed graph-iteration in profiles/pmc_traffic.json; counters cannot be read
+            # from inside this process, so the stored figure is scaled to this run's iterations
+            traffic, traffic_src = None, None
+            try:
+                pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(args.workload)
+                if pmc:
+                    gi = float(iters_acc.item()) if early_stop else float(len(r)) * args.mpm_iters
+                    traffic = pmc["hbm_bytes_per_graph_iteration"] * gi / max(1, n_iter)
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except OSError:
+                pass
+            roof = {"kernel": "mpm_stream_kernel", "bound": "hbm", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "launches": int(n_iter), "avg_launch_ms": ms_iter / max(1, n_iter),
                     "alg_bytes_per_launch": alg_bytes / max(1, n_iter),
                     "mean_mpm_iters_per_graph": float(iters_acc.item()) / (args.steps * per_gpu),

@@ -268,6 +268,9 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 //     error word instead of hanging.
 // Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
 // everything else instead of costing one under-filled launch per iteration.
+#ifndef MPM_U
+#define MPM_U 4
+#endif
 #define MPM_NULL_ITEM 0xFFFFFFFFu
 #define MPM_SPIN_LIMIT (1u << 21)
 
@@ -342,9 +345,9 @@ __global__ void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__
       }
       __syncthreads();
       const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
-      if ((R & 3) == 0) mpm_iter_body<4, 4>(slab, R, i, Xs, T, nsrow);
-      else if ((R & 1) == 0) mpm_iter_body<2, 4>(slab, R, i, Xs, T, nsrow);
-      else mpm_iter_body<1, 4>(slab, R, i, Xs, T, nsrow);
+      if ((R & 3) == 0) mpm_iter_body<4, MPM_U>(slab, R, i, Xs, T, nsrow);
+      else if ((R & 1) == 0) mpm_iter_body<2, MPM_U>(slab, R, i, Xs, T, nsrow);
+      else mpm_iter_body<1, MPM_U>(slab, R, i, Xs, T, nsrow);
       __syncthreads();
       float *Xn = Xnew + g * strideXnew;
       for (int p = tid; p < R; p += nt) {

@@ -12,7 +12,11 @@ from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libgvae_hip.so"
+import os
+
+# GVAE_HIP_LIB selects another build of the same library (kernel tuning experiments)
+_LIB_PATH = Path(os.environ.get("GVAE_HIP_LIB") or
+                 Path(__file__).resolve().parent / "lib" / "libgvae_hip.so")
 _lib = None
 
 MAX_NODES_LDS = 128
