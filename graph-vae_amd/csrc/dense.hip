@@ -15,23 +15,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------
 // GEMM: 64x64 block tile, 4 wavefronts, each wavefront one 32x32 accumulator tile
-// fed by v_mfma_f32_32x32x2_f32; K staged through LDS 16 at a time.
+// fed by v_mfma_f32_32x32x2_f32; K staged through LDS 64 at a time.
 // Operand lane map (32x32x2): lane l supplies A[m = l&31][k = l>>5] and
 // B[k = l>>5][n = l&31]; accumulator register r of lane l is
 // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 // ---------------------------------------------------------------------------
 #define GT_M 64
 #define GT_N 64
-#define GT_K 16
+#define GT_K 64
 #define GT_LD 68
 
+// These GEMMs are small and latency-bound (a few K-tiles per work-group), so a tile's global
+// loads (16 + 16 scalars per lane) are all issued back to back: one memory round trip per
+// 64-deep K-tile; long K is cut with split-K on the host side so that the chip is filled.
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
   __shared__ float As[GT_K][GT_LD];
   __shared__ float Bs[GT_K][GT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
-  int z = blockIdx.z;
+  const int z = blockIdx.z;
   const float *A = d.A, *B = d.B;
   float *C = d.C;
   int k_begin = 0, k_end = d.K;
@@ -47,28 +50,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
   }
   f32x16 acc = {0};
   const bool a_kfast = (d.a_cs == 1), b_nfast = (d.b_cs == 1);
+  // lane -> (row, k) of the A tile and (k, col) of the B tile; the fast-varying index follows
+  // the operand's unit stride so that a wave's loads are contiguous
+  const int am = a_kfast ? (tid >> 6) : (tid & 63), ak = a_kfast ? (tid & 63) : (tid >> 6);
+  const int bn = b_nfast ? (tid & 63) : (tid >> 6), bk = b_nfast ? (tid >> 6) : (tid & 63);
   for (int k0 = k_begin; k0 < k_end; k0 += GT_K) {
+    float ra[16], rb[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int m, k;
-      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * r; }
-      else { m = tid & 63; k = (tid >> 6) + 4 * r; }
+    for (int r = 0; r < 16; ++r) {
+      const int m = a_kfast ? am + 4 * r : am, k = a_kfast ? ak : ak + 4 * r;
       const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < d.M && gk < k_end) ? A[gm * d.a_rs + gk * d.a_cs] : 0.0f;
-      int n, kb;
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * r; }
-      else { kb = tid & 15; n = (tid >> 4) + 16 * r; }
+      ra[r] = (gm < d.M && gk < k_end) ? A[gm * d.a_rs + gk * d.a_cs] : 0.0f;
+      const int n = b_nfast ? bn : bn + 4 * r, kb = b_nfast ? bk + 4 * r : bk;
       const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb][n] = (gn < d.N && gkb < k_end) ? B[gkb * d.b_rs + gn * d.b_cs] : 0.0f;
+      rb[r] = (gn < d.N && gkb < k_end) ? B[gkb * d.b_rs + gn * d.b_cs] : 0.0f;
+    }
+    __syncthreads();  // previous tile's MFMA reads are done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = a_kfast ? am + 4 * r : am, k = a_kfast ? ak : ak + 4 * r;
+      As[k][m] = ra[r];
+      const int n = b_nfast ? bn : bn + 4 * r, kb = b_nfast ? bk + 4 * r : bk;
+      Bs[kb][n] = rb[r];
     }
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < GT_K; kk += 2) {
+    const int kmax = min(GT_K, k_end - k0);
+    for (int kk = 0; kk < kmax; kk += 2) {
       const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
       const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    __syncthreads();
   }
   const int col = n0 + wn + (lane & 31);
   if (col >= d.N) return;

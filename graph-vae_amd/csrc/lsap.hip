@@ -18,16 +18,28 @@
 
 namespace gvae {
 
-__device__ __forceinline__ double wave_min_f64(double v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+// Wave-wide reductions on the data-parallel-primitive path (no LDS traffic): an xor butterfly
+// inside each row of 16 lanes (quad permutes, then half-row and row mirrors), then the four
+// row results are combined through scalar lane reads.  Every lane ends up with the result.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
 }
-__device__ __forceinline__ int wave_min_i32(int v) {
-  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+__device__ __forceinline__ double min_f64(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ double read_lane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+  v = min_f64(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min_f64(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror
+  v = min_f64(v, dpp_f64<0x140>(v));  // row_mirror
+  return min_f64(min_f64(read_lane_f64(v, 0), read_lane_f64(v, 16)),
+                 min_f64(read_lane_f64(v, 32), read_lane_f64(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
@@ -90,27 +102,38 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ X, i
       if (lane == 0) SR[i] = 1;
       const double ui = u[i];
       const float *crow = cost + i * n;
+      // pass over the unscanned columns, two chunks of 64 lanes (n <= 128)
+      double sj[2];
+      int free_col[2];
       double lowest = INFINITY;
-      for (int it = lane; it < num_remaining; it += 64) {
-        const int j = remaining[it];
-        const double r = minVal + (double)(-crow[j]) - ui - v[j];
-        double sj = spc[j];
-        if (r < sj) { path[j] = i; spc[j] = r; sj = r; }
-        lowest = sj < lowest ? sj : lowest;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int it = c * 64 + lane;
+        sj[c] = INFINITY;
+        free_col[c] = 0;
+        if (it < num_remaining) {
+          const int j = remaining[it];
+          const double r = minVal + (double)(-crow[j]) - ui - v[j];
+          double cur_s = spc[j];
+          if (r < cur_s) { path[j] = i; spc[j] = r; cur_s = r; }
+          sj[c] = cur_s;
+          free_col[c] = row4col[j] == -1;
+          lowest = cur_s < lowest ? cur_s : lowest;
+        }
       }
       lowest = wave_min_f64(lowest);
       if (lowest == INFINITY) { fail = 1; break; }
-      // selection among columns at the minimum
+      // among the columns at the minimum: the last unassigned one in list order if there is
+      // one, else the first one in list order (what the sequential scan ends up with)
       int last_free = -1, first_any = 0x7fffffff;
-      for (int it = lane; it < num_remaining; it += 64) {
-        const int j = remaining[it];
-        if (spc[j] == lowest) {
-          first_any = min(first_any, it);
-          if (row4col[j] == -1) last_free = it;  // ascending it per lane: keeps the largest
-        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bool at_min = (c * 64 + lane < num_remaining) && sj[c] == lowest;
+        const unsigned long long bm = __ballot(at_min);
+        const unsigned long long bf = __ballot(at_min && free_col[c]);
+        if (bm != 0ull && first_any == 0x7fffffff) first_any = c * 64 + __ffsll((long long)bm) - 1;
+        if (bf != 0ull) last_free = c * 64 + 63 - __clzll((long long)bf);
       }
-      last_free = wave_max_i32(last_free);
-      first_any = wave_min_i32(first_any);
       const int index = last_free >= 0 ? last_free : first_any;
       minVal = lowest;
       const int j = remaining[index];

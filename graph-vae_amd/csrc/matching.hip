@@ -120,12 +120,14 @@ __global__ __launch_bounds__(256) void edge_sim_kernel(const float *__restrict__
 // floats per lane per load, so a wave's load instruction covers 64/lpr consecutive
 // rows = one contiguous run of the slab.  The max over b is exact in any order.
 // ---------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <int V>
 struct VecT;
 template <>
-struct VecT<4> { using type = float4; };
+struct VecT<4> { using type = f32x4_t; };
 template <>
-struct VecT<2> { using type = float2; };
+struct VecT<2> { using type = f32x2_t; };
 template <>
 struct VecT<1> { using type = float; };
 
@@ -134,6 +136,21 @@ __device__ __forceinline__ void vec_to_arr(const typename VecT<V>::type &v, floa
   if constexpr (V == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
   else if constexpr (V == 2) { o[0] = v.x; o[1] = v.y; }
   else { o[0] = v; }
+}
+
+// S is read exactly once per iteration and is far larger than the caches: stream it with the
+// non-temporal policy (GVAE_STREAM_NT=0 builds the default-policy variant)
+#ifndef GVAE_STREAM_NT
+#define GVAE_STREAM_NT 1
+#endif
+template <int V>
+__device__ __forceinline__ typename VecT<V>::type stream_load(const float *p) {
+  using vec_t = typename VecT<V>::type;
+#if GVAE_STREAM_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(p));
+#else
+  return *reinterpret_cast<const vec_t *>(p);
+#endif
 }
 
 template <int V, int U>
@@ -165,7 +182,7 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
         ju[u] = j; au[u] = a;
         const int r_u = row + u * rows_per_pass;
         if (r_u < R2 && lr < cols)
-          sv[u] = *reinterpret_cast<const vec_t *>(slab + (int64_t)r_u * R + lr * V);
+          sv[u] = stream_load<V>(slab + (int64_t)r_u * R + lr * V);
         a += da; j += dj;
         if (a >= R) { a -= R; ++j; }
       }
@@ -195,7 +212,7 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
         if (r_u < R2) {
           for (int c = lr; c < cols; c += lpr) {
             float s[V];
-            vec_to_arr<V>(*reinterpret_cast<const vec_t *>(slab + (int64_t)r_u * R + c * V), s);
+            vec_to_arr<V>(stream_load<V>(slab + (int64_t)r_u * R + c * V), s);
             const float *xr = Xs + j * R + c * V;
 #pragma unroll
             for (int v = 0; v < V; ++v) mm = fmaxf(mm, s[v] * xr[v]);

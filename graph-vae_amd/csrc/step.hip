@@ -70,10 +70,12 @@ static Workspace carve(const gvae_dims *d, int B, char *base) {
   w.dmu = take((int64_t)B * Z); w.dlv = take((int64_t)B * Z); w.dgvec = take(BH);
   w.dAct = take(BNH); w.dY = take(BNH); w.dH0 = take(BNH);
   w.dgam_p = take(BH); w.dbet_p = take(BH); w.dbias_p = take(BH);
-  int64_t sk = (int64_t)kMaxSplits * H * (H > F ? H : F);
-  const int64_t sk2 = (int64_t)kMaxSplits * B * H;
-  if (sk2 > sk) sk = sk2;
-  w.splitk = take(sk);
+  // split-K partials: splits <= ceil(512 / tiles) and tiles >= M*N/4096, so
+  // splits*M*N <= 512*4096 + M*N for every GEMM that is split
+  int64_t mn = U * H;
+  const int64_t cand[] = {(int64_t)B * H, H * H, H * F, N * H, Z * H, (int64_t)B * Z};
+  for (int64_t c : cand) mn = c > mn ? c : mn;
+  w.splitk = take(512 * 4096 + mn);
   w.status = reinterpret_cast<int32_t *>(take(B));
   w.mpm_ws = reinterpret_cast<char *>(take((gvae_mpm_stream_ws_bytes(B, (int)N) + 3) / 4));
   w.bytes = off;
@@ -91,11 +93,14 @@ static Params bind(const gvae_dims *d, const float *flat) {
   return P;
 }
 
+// Split-K factor: enough work-groups to fill the chip (256 CUs), at least two 64-deep K-tiles
+// per split.
 static int pick_splits(int M, int N, int K) {
   const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
-  if (tiles >= 128 || K < 1024) return 1;
-  int s = K / 512;
-  if (s * tiles > 1024) s = 1024 / tiles;
+  if (tiles >= 256 || K < 256) return 1;
+  int s = K / 128;
+  const int want = ceil_div(512, tiles);
+  if (s > want) s = want;
   if (s > kMaxSplits) s = kMaxSplits;
   return s < 1 ? 1 : s;
 }
