@@ -239,11 +239,20 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
 __device__ __forceinline__ float norm_chain(const float *x, int n, int lane, float acc) {
+  // the fused chain itself is serial; keep the next 8 operands in flight while it runs
   int d = 0;
-  for (; d + 64 <= n; d += 64) {
-    float v[8];
+  if (n >= 64) {
+    float v[8], w[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = x[d + 8 * t + lane];
+    for (int t = 0; t < 8; ++t) v[t] = x[8 * t + lane];
+    for (d = 64; d + 64 <= n; d += 64) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) w[t] = x[d + 8 * t + lane];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = __fmaf_rn(v[t], v[t], acc);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = w[t];
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc = __fmaf_rn(v[t], v[t], acc);
   }
@@ -471,10 +480,6 @@ __global__ void mpm_queue_init_kernel(MpmQueue q, const int32_t *__restrict__ Ra
   if (t == 0) *Q_TAIL(q) = n_graphs * r_max;
 }
 
-__global__ void zero_i32_kernel(int32_t *a, int n) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) a[t] = 0;
-}
 
 // ---------------------------------------------------------------------------
 // Fused S-free MPM: one work-group per graph, Pt (P transposed, zero diagonal),
@@ -485,32 +490,102 @@ __global__ void zero_i32_kernel(int32_t *a, int n) {
 //   X = Xn / ||Xn||_2 ; stop when max|X - Xprev| < tol
 // The previous X lives in the caller's d_X buffer (global), the new one in LDS.
 // ---------------------------------------------------------------------------
-__global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__restrict__ P,
-                                 const float *__restrict__ NS, const int32_t *__restrict__ Rarr,
-                                 int ld, int64_t stride, float *__restrict__ X, int ldx,
-                                 int64_t strideX, int iters, float tol, int early_stop,
-                                 int32_t *__restrict__ iters_done) {
-  extern __shared__ float lds[];
+
+// Diagnostic build (-DGVAE_FUSED_STAMPS): work-group 0 prints the cycles it spent per phase.
+#ifdef GVAE_FUSED_STAMPS
+#define STAMP(k) do { __syncthreads(); const long long t_ = __builtin_readcyclecounter(); \
+                      st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+// canonical column sums of NCH rows that share one column a: chain c adds, for j = 0..R-1 in
+// the canonical order, M[j,a] if bit j of mask row c is set and an exact +0 otherwise.  The
+// M values are loaded once per j (not once per chain) and the NCH chains are independent, so
+// the LDS latency and the add latency overlap.
+template <int NCH>
+__device__ __forceinline__ void cascade_chains(const float *__restrict__ Mcol, int R,
+                                               const uint32_t *const (&bits)[NCH],
+                                               float (&out)[NCH]) {
+  float l0[NCH], l1[NCH], l2[NCH], l3[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) l0[c] = l1[c] = l2[c] = l3[c] = 0.f;
+  int i = 0;
+  while (i + 16 <= R) {
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = Mcol[(i + t) * R];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t w = bits[c][i >> 5] >> (i & 31);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) l0[c] += ((w >> t) & 1u) ? v[t] : 0.0f;
+    }
+    i += 16;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      l1[c] += l0[c];
+      l0[c] = 0.f;
+    }
+    if ((i & 0xF0) == 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        l2[c] += l1[c];
+        l1[c] = 0.f;
+      }
+      if ((i & 0xF00) == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          l3[c] += l2[c];
+          l2[c] = 0.f;
+        }
+      }
+    }
+  }
+  for (; i < R; ++i) {
+    const float v = Mcol[i * R];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) l0[c] += ((bits[c][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    l0[c] += l1[c];
+    l0[c] += l2[c];
+    l0[c] += l3[c];
+    out[c] = l0[c];
+  }
+}
+
+// LDS: Pp (R rows of P with the diagonal zeroed, row stride R+4 so that lanes holding
+// consecutive rows read 16-byte pieces conflict-free), X (R*R), M (R*R), A as bit rows.
+// NT = work-group size, KMAX = rows per lane (ceil(R / floor(NT / R)) <= KMAX must hold).
+template <int NT, int KMAX>
+__global__ __launch_bounds__(NT) void mpm_fused_kernel(
+    const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
+    const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
+    int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[16];
   __shared__ float s_nrm;
   __shared__ int s_stop;
-  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  constexpr int nt = NT;
   const int R = Rarr[g];
   if (R <= 0) {
     if (tid == 0) iters_done[g] = 0;
     return;
   }
-  const int R2 = R * R, W = (R + 31) >> 5;
-  float *Pt = lds;                 // R*R, Pt[b*R + a] = P[a,b], 0 on the diagonal
-  float *Xs = Pt + R2;             // R*R
+  const int R2 = R * R, W = (R + 31) >> 5, PS = R + 4;
+  float *Pp = lds;                 // R * (R+4): Pp[a*PS + b] = P[a,b], 0 for a == b
+  float *Xs = Pp + R * PS;         // R*R
   float *M = Xs + R2;              // R*R
-  uint32_t *Abits = reinterpret_cast<uint32_t *>(M + R2);  // R*W
+  uint32_t *Abits = reinterpret_cast<uint32_t *>(M + R2);  // R*W, bit j of row i: A[i,j] != 0, j != i
   const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
   float *Xg = X + g * strideX;
 
   for (int e = tid; e < R2; e += nt) {
     const int r = e / R, c = e - r * R;
-    Pt[c * R + r] = (r == c) ? 0.0f : Pg[(int64_t)r * ld + c];
+    Pp[r * PS + c] = (r == c) ? 0.0f : Pg[(int64_t)r * ld + c];
     Xs[e] = Xg[(int64_t)r * ldx + c];
   }
   for (int e = tid; e < R * W; e += nt) {
@@ -522,30 +597,116 @@ __global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__res
     }
     Abits[e] = bits;
   }
+  // element ownership for the column sums and the update: lane (ta, tj) owns column a = ta and
+  // rows i = tj + k*TJ; node-similarity factor and previous X of those stay in registers
+  const int TJ = nt / R;
+  const int ta = tid % R, tj = tid / R;
+  const bool owner = tj < TJ;
+  float nsv[KMAX], xprev[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = tj + k * TJ;
+    nsv[k] = 0.f;
+    xprev[k] = 0.f;
+    if (owner && i < R) {
+      nsv[k] = NSg[(int64_t)i * ld + ta];
+      xprev[k] = Xg[(int64_t)i * ldx + ta];
+    }
+  }
   __syncthreads();
 
   const int n8 = R2 & ~7;
+  const int JQ = (R + 3) >> 2;          // groups of 4 consecutive rows j
+  const bool vec4 = (R & 3) == 0;
   int done = 0;
+#ifdef GVAE_FUSED_STAMPS
+  long long st_acc[5] = {0, 0, 0, 0, 0};
+  long long st_last = __builtin_readcyclecounter();
+#endif
   for (int it = 0; it < iters; ++it) {
-    // phase 1: M = maxprod(X, Pt)
-    for (int e = tid; e < R2; e += nt) {
-      const int j = e / R, a = e - j * R;
-      const float *xr = Xs + j * R;
-      const float *pc = Pt + a;
-      float m = 0.0f;
-      for (int b = 0; b < R; ++b) m = fmaxf(m, pc[b * R] * xr[b]);
-      M[e] = m;
+    STAMP(4);
+    // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b]  (>= 0; Pp[a,a] = 0).  A lane takes one column a
+    // and four consecutive rows j at a time: per 4 values of b it reads one 16-byte piece of
+    // Pp's row a and four (wave-broadcast) pieces of X.
+    for (int w = tid; w < R * JQ; w += nt) {
+      const int jq = w / R, a = w - jq * R;
+      const int j0 = jq * 4;
+      const float *pr = Pp + a * PS;
+      float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+      const float *x0 = Xs + j0 * R;
+      const float *x1 = Xs + min(j0 + 1, R - 1) * R;
+      const float *x2 = Xs + min(j0 + 2, R - 1) * R;
+      const float *x3 = Xs + min(j0 + 3, R - 1) * R;
+      if (vec4) {
+        for (int b = 0; b < R; b += 4) {
+          const f32x4_t p = *reinterpret_cast<const f32x4_t *>(pr + b);
+          const f32x4_t a0 = *reinterpret_cast<const f32x4_t *>(x0 + b);
+          const f32x4_t a1 = *reinterpret_cast<const f32x4_t *>(x1 + b);
+          const f32x4_t a2 = *reinterpret_cast<const f32x4_t *>(x2 + b);
+          const f32x4_t a3 = *reinterpret_cast<const f32x4_t *>(x3 + b);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            m0 = fmaxf(m0, p[q] * a0[q]);
+            m1 = fmaxf(m1, p[q] * a1[q]);
+            m2 = fmaxf(m2, p[q] * a2[q]);
+            m3 = fmaxf(m3, p[q] * a3[q]);
+          }
+        }
+      } else {
+        for (int b = 0; b < R; ++b) {
+          const float p = pr[b];
+          m0 = fmaxf(m0, p * x0[b]);
+          m1 = fmaxf(m1, p * x1[b]);
+          m2 = fmaxf(m2, p * x2[b]);
+          m3 = fmaxf(m3, p * x3[b]);
+        }
+      }
+      M[j0 * R + a] = m0;
+      if (j0 + 1 < R) M[(j0 + 1) * R + a] = m1;
+      if (j0 + 2 < R) M[(j0 + 2) * R + a] = m2;
+      if (j0 + 3 < R) M[(j0 + 3) * R + a] = m3;
     }
     __syncthreads();
-    // phase 2: Xn (written over Xs; the previous X stays in global memory)
-    for (int e = tid; e < R2; e += nt) {
-      const int i = e / R, a = e - i * R;
-      const uint32_t *ab = Abits + i * W;
-      const float et = column_sum(
-          [&](int jj) { return ((ab[jj >> 5] >> (jj & 31)) & 1u) ? M[jj * R + a] : 0.0f; }, a, R);
-      Xs[e] = Xs[e] * NSg[(int64_t)i * ld + a] + et;
+    STAMP(0);
+    // phase 2: Xn[i,a] = Xprev[i,a]*NS[i,a] + sum_{j: A[i,j]} M[j,a]  (canonical column sums),
+    // written over Xs
+    if (owner) {
+      const float *Mcol = M + ta;
+      if (column_uses_cascade(ta, R)) {
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+          if (tj + k0 * TJ < R) {
+            const uint32_t *br[4];
+            float et[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) br[c] = Abits + min(tj + (k0 + c) * TJ, R - 1) * W;
+            cascade_chains<4>(Mcol, R, br, et);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int i = tj + (k0 + c) * TJ;
+              if (i < R) Xs[i * R + ta] = xprev[k0 + c] * nsv[k0 + c] + et[c];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          const int i = tj + k * TJ;
+          if (i < R) {
+            const uint32_t *ab = Abits + i * W;
+            const float et = ilp4_sum(
+                [&](int jj) {
+                  const float v = Mcol[jj * R];
+                  return ((ab[jj >> 5] >> (jj & 31)) & 1u) ? v : 0.0f;
+                },
+                R);
+            Xs[i * R + ta] = xprev[k] * nsv[k] + et;
+          }
+        }
+      }
     }
     __syncthreads();
+    STAMP(1);
     // phase 3: canonical norm over the contiguous R*R block
     if (tid < 64) {
       float acc = 0.f;
@@ -554,17 +715,21 @@ __global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__res
       if (tid == 0) s_nrm = nrm;
     }
     __syncthreads();
+    STAMP(2);
     const float nrm = s_nrm;
     float dmax = 0.f;
     bool isnan_any = false;
-    for (int e = tid; e < R2; e += nt) {
-      const int r = e / R, c = e - r * R;
-      const float v = Xs[e] / nrm;
-      const float d = fabsf(v - Xg[(int64_t)r * ldx + c]);
-      isnan_any |= (d != d);
-      dmax = fmaxf(dmax, d);
-      Xs[e] = v;
-      Xg[(int64_t)r * ldx + c] = v;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = tj + k * TJ;
+      if (owner && i < R) {
+        const float v = Xs[i * R + ta] / nrm;
+        const float d = fabsf(v - xprev[k]);
+        isnan_any |= (d != d);
+        dmax = fmaxf(dmax, d);
+        Xs[i * R + ta] = v;
+        xprev[k] = v;
+      }
     }
     if (isnan_any) dmax = INFINITY;
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
@@ -576,10 +741,26 @@ __global__ void mpm_fused_kernel(const float *__restrict__ A, const float *__res
       s_stop = (early_stop && d < tol) ? 1 : 0;
     }
     __syncthreads();
+    STAMP(3);
     ++done;
     if (s_stop) break;
   }
+#ifdef GVAE_FUSED_STAMPS
+  if (g == 0 && tid == 0)
+    printf("fused stamps R=%d iters=%d: maxprod %lld  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
+           R, done, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
+#endif
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = tj + k * TJ;
+    if (owner && i < R) Xg[(int64_t)i * ldx + ta] = xprev[k];
+  }
   if (tid == 0) iters_done[g] = done;
+}
+
+__global__ void zero_i32_kernel(int32_t *a, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) a[t] = 0;
 }
 
 }  // namespace gvae
@@ -689,21 +870,29 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
                "mpm_fused: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "mpm_fused: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", n_graphs, r_max, ld, ldx);
-  const size_t lds = 12 * (size_t)r_max * r_max + 4 * (size_t)r_max * ((r_max + 31) / 32);
+  const size_t lds = 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
+                     4 * (size_t)r_max * ((r_max + 31) / 32);
   GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
                "mpm_fused: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", r_max, lds);
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)mpm_fused_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_fused: cannot reserve %zu bytes of LDS: %s", lds,
-                 hipGetErrorString(e));
-  }
-  const int nt = r_max <= 32 ? 256 : (r_max <= 64 ? 512 : 1024);
   ProfileScope ps(F_MPM_FUSED, s);
-  hipLaunchKernelGGL(mpm_fused_kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld,
-                     stride, d_X, ldx, strideX, iters, tol, early_stop, d_iters_done);
+  auto launch = [&](auto kernel, int nt) -> int {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_fused: cannot reserve %zu bytes of LDS: %s",
+                   lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld, stride, d_X,
+                       ldx, strideX, iters, tol, early_stop, d_iters_done);
+    return GVAE_OK;
+  };
+  int rc;
+  if (r_max <= 32) rc = launch(mpm_fused_kernel<256, 4>, 256);
+  else if (r_max <= 64) rc = launch(mpm_fused_kernel<512, 8>, 512);
+  else rc = launch(mpm_fused_kernel<1024, 16>, 1024);
+  if (rc) return rc;
   return check_launch("mpm_fused");
 }
 

@@ -85,7 +85,7 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R
  * gvae_edge_sim + gvae_mpm_stream when A is 0/1 with unit diagonal and P >= 0,
  * using  max_b S[i,j,a,b] X[j,b] = A[i,j] * max_{b!=a} P[a,b] X[j,b]  (j != i).
  * One work-group per graph, everything resident in LDS.  r_max <= GVAE_MAX_NODES_LDS
- * (and the LDS budget: 12*r_max^2 + 4*r_max*ceil(r_max/32) bytes <= 160 KiB).
+ * (and the LDS budget: 12*r_max^2 + 16*r_max + 4*r_max*ceil(r_max/32) bytes <= 159 KiB).
  * No counterpart in the reference (it always materialises S).
  */
 int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
