@@ -153,88 +153,97 @@ __device__ __forceinline__ typename VecT<V>::type stream_load(const float *p) {
 #endif
 }
 
-template <int V, int U>
-__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int i,
-                                              const float *Xs, float *T, float *nsrow) {
+// max over the 2^lpr_log2 adjacent lanes that share one row; every lane of the group ends
+// up with the group's maximum.  DPP moves up to 16 lanes, ds_bpermute beyond.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group_max(float m, int lpr_log2) {
+  if (lpr_log2 >= 1) m = fmaxf(m, dpp_mov<0xB1>(m));   // quad_perm [1,0,3,2]
+  if (lpr_log2 >= 2) m = fmaxf(m, dpp_mov<0x4E>(m));   // quad_perm [2,3,0,1]
+  if (lpr_log2 >= 3) m = fmaxf(m, dpp_mov<0x141>(m));  // row_half_mirror
+  if (lpr_log2 >= 4) m = fmaxf(m, dpp_mov<0x140>(m));  // row_mirror
+  if (lpr_log2 >= 5) m = fmaxf(m, __shfl_xor(m, 16, 64));
+  if (lpr_log2 >= 6) m = fmaxf(m, __shfl_xor(m, 32, 64));
+  return m;
+}
+
+// Rows are R floats = cols vectors of V floats.  A row is shared by lpr = 2^lpr_log2 adjacent
+// lanes; lane lr of the group takes the vectors lr, lr + lpr, ... (PASSES of them; indices past
+// the row end are clamped to its last vector: a duplicate cannot change a maximum).  RB rows per
+// group are in flight at a time, so a lane has RB*PASSES independent loads outstanding.
+// T[row] receives max_b S[i,j,a,b]*X[j,b] for every row (j,a), the row j == i included.
+template <int V, int PASSES, int RB>
+__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int lpr_log2,
+                                              const float *Xs, float *T) {
   using vec_t = typename VecT<V>::type;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int R2 = R * R;
   const int cols = R / V;
-  int lpr_log2 = 0;
-  while ((1 << lpr_log2) < cols && lpr_log2 < 6) ++lpr_log2;
   const int lpr = 1 << lpr_log2;
   const int lr = tid & (lpr - 1);
-  const int rows_per_pass = nt >> lpr_log2;
+  const int rpp = nt >> lpr_log2;       // rows per step of the whole work-group
   const int row0 = tid >> lpr_log2;
+  int coff[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) coff[p] = min(lr + p * lpr, cols - 1) * V;
 
-  // (j,a) of this thread's first row; advanced incrementally, no division in the loop
-  int j = row0 / R, a = row0 - j * R;
-  const int dj = rows_per_pass / R, da = rows_per_pass - dj * R;
+  // (j*R, a) of this group's current row, advanced incrementally (no division in the loop)
+  int a = row0 % R, jR = row0 - a;
+  const int dj = rpp / R, da = rpp - dj * R, djR = dj * R;
+  const int jR_last = R2 - R;
 
-  for (int row = row0; row < R2; row += rows_per_pass * U) {
-    float m[U];
-    int ju[U], au[U];
-    if (cols <= lpr) {
-      // single vector per lane per row: issue all U loads before any use
-      vec_t sv[U];
+  for (int row = row0; row < R2; row += rpp * RB) {
+    vec_t sv[RB][PASSES];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ju[u] = j; au[u] = a;
-        const int r_u = row + u * rows_per_pass;
-        if (r_u < R2 && lr < cols)
-          sv[u] = stream_load<V>(slab + (int64_t)r_u * R + lr * V);
-        a += da; j += dj;
-        if (a >= R) { a -= R; ++j; }
-      }
+    for (int rb = 0; rb < RB; ++rb) {
+      const int r = min(row + rb * rpp, R2 - 1);
+      const float *src = slab + (unsigned)(r * R);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int r_u = row + u * rows_per_pass;
-        float mm = -INFINITY;
-        if (r_u < R2 && lr < cols) {
-          float s[V];
-          vec_to_arr<V>(sv[u], s);
-          const float *xr = Xs + ju[u] * R + lr * V;
-#pragma unroll
-          for (int v = 0; v < V; ++v) mm = fmaxf(mm, s[v] * xr[v]);
-          if (ju[u] == i) {
-            const int bb = au[u] - lr * V;
-            if (bb >= 0 && bb < V) nsrow[au[u]] = s[bb];
-          }
-        }
-        m[u] = mm;
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ju[u] = j; au[u] = a;
-        const int r_u = row + u * rows_per_pass;
-        float mm = -INFINITY;
-        if (r_u < R2) {
-          for (int c = lr; c < cols; c += lpr) {
-            float s[V];
-            vec_to_arr<V>(stream_load<V>(slab + (int64_t)r_u * R + c * V), s);
-            const float *xr = Xs + j * R + c * V;
-#pragma unroll
-            for (int v = 0; v < V; ++v) mm = fmaxf(mm, s[v] * xr[v]);
-            if (j == i) {
-              const int bb = a - c * V;
-              if (bb >= 0 && bb < V) nsrow[a] = s[bb];
-            }
-          }
-        }
-        m[u] = mm;
-        a += da; j += dj;
-        if (a >= R) { a -= R; ++j; }
-      }
+      for (int p = 0; p < PASSES; ++p) sv[rb][p] = stream_load<V>(src + coff[p]);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float mm = m[u];
-      for (int off = lpr >> 1; off > 0; off >>= 1) mm = fmaxf(mm, __shfl_xor(mm, off, 64));
-      const int r_u = row + u * rows_per_pass;
-      if (lr == 0 && r_u < R2) T[r_u] = (ju[u] == i) ? 0.0f : mm;
+    for (int rb = 0; rb < RB; ++rb) {
+      const float *xr = Xs + min(jR, jR_last);
+      float m = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        float s[V], x[V];
+        vec_to_arr<V>(sv[rb][p], s);
+        vec_to_arr<V>(*reinterpret_cast<const vec_t *>(xr + coff[p]), x);
+#pragma unroll
+        for (int v = 0; v < V; ++v) m = fmaxf(m, s[v] * x[v]);
+      }
+      m = group_max(m, lpr_log2);
+      const int r_u = row + rb * rpp;
+      if (lr == 0 && r_u < R2) T[r_u] = m;
+      a += da;
+      jR += djR;
+      if (a >= R) {
+        a -= R;
+        jR += R;
+      }
     }
   }
+}
+
+// picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
+// 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
+template <int V>
+__device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R,
+                                                  const float *Xs, float *T) {
+  const int cols = R / V;
+  int lpr_log2 = 0;
+  constexpr int kBase = V == 4 ? 3 : (V == 2 ? 4 : 5);
+  while ((1 << lpr_log2) < cols && lpr_log2 < kBase) ++lpr_log2;
+  while ((cols + (1 << lpr_log2) - 1) >> lpr_log2 > 4) ++lpr_log2;
+  const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
+  if (passes == 1) mpm_iter_body<V, 1, 4>(slab, R, lpr_log2, Xs, T);
+  else if (passes == 2) mpm_iter_body<V, 2, 2>(slab, R, lpr_log2, Xs, T);
+  else if (passes == 3) mpm_iter_body<V, 3, 2>(slab, R, lpr_log2, Xs, T);
+  else mpm_iter_body<V, 4, 1>(slab, R, lpr_log2, Xs, T);
 }
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
@@ -294,9 +303,6 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 //     error word instead of hanging.
 // Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
 // everything else instead of costing one under-filled launch per iteration.
-#ifndef MPM_U
-#define MPM_U 4
-#endif
 #define MPM_NULL_ITEM 0xFFFFFFFFu
 #define MPM_SPIN_LIMIT (1u << 21)
 
@@ -311,7 +317,8 @@ struct MpmQueue {
 #define Q_REMAIN(q) ((q).words + 64)
 #define Q_ERROR(q) ((q).words + 96)
 
-__global__ void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
+// 64 VGPRs: 8 waves per SIMD, so that eight 256-thread work-groups stream per compute unit
+__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
                                   float *__restrict__ Xnew, int64_t strideXnew, float tol,
@@ -365,19 +372,23 @@ __global__ void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__
       float *T = lds + R2;        // R*R
       float *nsrow = T + R2;      // R
       float *Xg = X + g * strideX;
+      const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
       for (int e = tid; e < R2; e += nt) {
         const int r = e / R, c = e - r * R;
         Xs[e] = Xg[(int64_t)r * ldx + c];
       }
+      // S[i,i,a,a], the factor of X[i,a] in the update
+      for (int p = tid; p < R; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * R + p];
       __syncthreads();
-      const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
-      if ((R & 3) == 0) mpm_iter_body<4, MPM_U>(slab, R, i, Xs, T, nsrow);
-      else if ((R & 1) == 0) mpm_iter_body<2, MPM_U>(slab, R, i, Xs, T, nsrow);
-      else mpm_iter_body<1, MPM_U>(slab, R, i, Xs, T, nsrow);
+      if ((R & 3) == 0) mpm_iter_dispatch<4>(slab, R, Xs, T);
+      else if ((R & 1) == 0) mpm_iter_dispatch<2>(slab, R, Xs, T);
+      else mpm_iter_dispatch<1>(slab, R, Xs, T);
       __syncthreads();
       float *Xn = Xnew + g * strideXnew;
       for (int p = tid; p < R; p += nt) {
-        const float et = column_sum([&](int jj) { return T[jj * R + p]; }, p, R);
+        // the row j == i does not take part in the sum: an exact +0 at its position
+        const float et =
+            column_sum([&](int jj) { return jj == i ? 0.0f : T[jj * R + p]; }, p, R);
         // write-through store (no release fence needed for a write-through payload)
         __hip_atomic_store(&Xn[i * R + p], Xs[i * R + p] * nsrow[p] + et, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
