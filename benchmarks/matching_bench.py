@@ -1,5 +1,5 @@
 """Micro-benchmark of the matching kernels (device-resident inputs).
-usage: python benchmarks/matching_bench.py [N] [B] [iters]"""
+usage: python benchmarks/matching_bench.py [N] [B] [iters] [early_stop 0|1] [padded S rows 0|1]"""
 import sys
 import time
 from pathlib import Path
@@ -16,6 +16,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     es = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
+    layout = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(0)
     up = torch.triu((torch.rand(B, N, N, generator=gen) < 0.5).float(), 1)
@@ -25,7 +26,7 @@ def main():
     Rh = [N] * B
     R = torch.tensor(Rh, dtype=torch.int32, device=dev)
     NS = _hip.node_sim(A, P, R)
-    S, S_off = _hip.edge_sim(A, P, NS, R, Rh)
+    S, S_off = _hip.edge_sim(A, P, NS, R, Rh, layout)
     torch.cuda.synchronize()
     sbytes = 4.0 * B * N ** 4
 
@@ -40,14 +41,14 @@ def main():
             ts.append(time.perf_counter() - t0)
         return min(ts)
 
-    t = timeit(lambda: _hip.edge_sim(A, P, NS, R, Rh))
+    t = timeit(lambda: _hip.edge_sim(A, P, NS, R, Rh, layout))
     print(f"edge_sim   N={N} B={B}: {t*1e3:8.3f} ms  {sbytes/t/1e12:6.3f} TB/s (write, incl. alloc)")
     ws = torch.empty(_hip.lib().gvae_mpm_stream_ws_bytes(B, N), dtype=torch.uint8, device=dev)
     X0 = _hip.x0_uniform(Rh, N, dev)
 
     def run_stream():
         X = X0.clone()
-        return _hip.mpm_stream(S, S_off, R, N, X, iters, 1e-4, es, ws=ws)
+        return _hip.mpm_stream(S, S_off, R, N, X, iters, 1e-4, es, ws=ws, layout=layout)
 
     _hip.profile_enable(True)
     _hip.profile_reset()
@@ -72,7 +73,7 @@ def main():
         t = timeit(run_fused)
         print(f"mpm_fused  wall {t*1e3:8.3f} ms  -> {B/t:9.1f} graphs/s")
     Xf = X0.clone()
-    _hip.mpm_stream(S, S_off, R, N, Xf, iters, 1e-4, es, ws=ws)
+    _hip.mpm_stream(S, S_off, R, N, Xf, iters, 1e-4, es, ws=ws, layout=layout)
     t = timeit(lambda: _hip.lsap(Xf, R, N))
     print(f"lsap       wall {t*1e3:8.3f} ms")
 

@@ -48,19 +48,21 @@ __global__ __launch_bounds__(256) void node_sim_kernel(const float *__restrict__
 
 // ---------------------------------------------------------------------------
 // edge-similarity tensor, materialised.  One work-group per (graph, i): it owns the
-// contiguous slab S[i,:,:,:] (R^3 floats).  Each thread keeps its piece of P in
-// registers and sweeps j, so every store instruction of a wave covers one
-// contiguous run of the slab.  V = floats per lane per store (4 when R % 4 == 0).
+// contiguous slab S[i,:,:,:] (R*R rows of RS floats; RS = R, or R rounded up to a
+// multiple of 4 in the padded layout, where the padding repeats the row's last element
+// so that it can never change a row maximum).  Each thread keeps its piece of P in
+// registers and sweeps j, so every store instruction of a wave covers one contiguous
+// run of the slab.  V = floats per lane per store (4 when RS % 4 == 0).
 //   S[i,j,a,b] = A[i,j]*P[a,b]  (i != j, a != b);  NS[i,a] (i == j, a == b);  else 0
 // ---------------------------------------------------------------------------
 template <int V>
 __device__ __forceinline__ void edge_sim_body(const float *__restrict__ Pg,
-                                              const float *__restrict__ NSg, int ld, int R, int i,
-                                              float *__restrict__ slab, const float *arow) {
+                                              const float *__restrict__ NSg, int ld, int R, int RS,
+                                              int i, float *__restrict__ slab, const float *arow) {
   const int tid = threadIdx.x;
-  const int64_t R2 = (int64_t)R * R;
+  const int64_t plane = (int64_t)R * RS;        // floats per (i,j) matrix
 
-  const int cols = R / V;                       // vector columns per row
+  const int cols = RS / V;                      // vector columns per row
   const int lpr = cols < 256 ? cols : 256;      // lanes per row
   const int rows_per_pass = 256 / lpr;
   const int rslot = tid / lpr, c0 = tid - rslot * lpr;
@@ -71,12 +73,12 @@ __device__ __forceinline__ void edge_sim_body(const float *__restrict__ Pg,
       const float nsv = NSg[(int64_t)i * ld + a];
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        const int b = c * V + v;
+        const int b = min(c * V + v, R - 1);    // padding repeats the row's last element
         p[v] = (b == a) ? 0.0f : Pg[(int64_t)a * ld + b];
         d[v] = (b == a) ? nsv : 0.0f;
       }
-      float *dst = slab + (int64_t)a * R + c * V;
-      for (int j = 0; j < R; ++j, dst += R2) {
+      float *dst = slab + (int64_t)a * RS + c * V;
+      for (int j = 0; j < R; ++j, dst += plane) {
         const float aij = arow[j];
         float o[V];
 #pragma unroll
@@ -93,23 +95,30 @@ __device__ __forceinline__ void edge_sim_body(const float *__restrict__ Pg,
   }
 }
 
+// row stride of a graph's S block: R floats (dense) or R rounded up to a multiple of 4
+__host__ __device__ __forceinline__ int s_row_stride(int R, int layout) {
+  return layout == GVAE_S_PADDED ? ((R + 3) & ~3) : R;
+}
+
 __global__ __launch_bounds__(256) void edge_sim_kernel(const float *__restrict__ A,
                                                        const float *__restrict__ P,
                                                        const float *__restrict__ NS,
                                                        const int32_t *__restrict__ Rarr, int ld,
-                                                       int64_t stride, float *__restrict__ S,
+                                                       int64_t stride, int layout,
+                                                       float *__restrict__ S,
                                                        const int64_t *__restrict__ S_off) {
   __shared__ float arow[1024];
   const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
   const int R = Rarr[g];
   if (i >= R) return;
+  const int RS = s_row_stride(R, layout);
   const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
-  float *slab = S + S_off[g] + (int64_t)i * R * R * R;
+  float *slab = S + S_off[g] + (int64_t)i * R * R * RS;
   for (int j = tid; j < R; j += 256) arow[j] = (j == i) ? 1.0f : Ag[(int64_t)i * ld + j];
   __syncthreads();
-  if ((R & 3) == 0) edge_sim_body<4>(Pg, NSg, ld, R, i, slab, arow);
-  else if ((R & 1) == 0) edge_sim_body<2>(Pg, NSg, ld, R, i, slab, arow);
-  else edge_sim_body<1>(Pg, NSg, ld, R, i, slab, arow);
+  if ((RS & 3) == 0) edge_sim_body<4>(Pg, NSg, ld, R, RS, i, slab, arow);
+  else if ((RS & 1) == 0) edge_sim_body<2>(Pg, NSg, ld, R, RS, i, slab, arow);
+  else edge_sim_body<1>(Pg, NSg, ld, R, RS, i, slab, arow);
 }
 
 // ---------------------------------------------------------------------------
@@ -170,18 +179,20 @@ __device__ __forceinline__ float group_max(float m, int lpr_log2) {
   return m;
 }
 
-// Rows are R floats = cols vectors of V floats.  A row is shared by lpr = 2^lpr_log2 adjacent
-// lanes; lane lr of the group takes the vectors lr, lr + lpr, ... (PASSES of them; indices past
-// the row end are clamped to its last vector: a duplicate cannot change a maximum).  RB rows per
-// group are in flight at a time, so a lane has RB*PASSES independent loads outstanding.
-// T[row] receives max_b S[i,j,a,b]*X[j,b] for every row (j,a), the row j == i included.
+// The slab holds R*R rows (j,a) of RS floats = cols vectors of V floats (RS = R, or R rounded
+// up to a multiple of 4 with the row's last element repeated).  A row is shared by
+// lpr = 2^lpr_log2 adjacent lanes; lane lr of the group takes the vectors lr, lr + lpr, ...
+// (PASSES of them; indices past the row end are clamped to its last vector: a duplicate
+// cannot change a maximum).  RB rows per group are in flight at a time, so a lane has
+// RB*PASSES independent loads outstanding.  Xs holds X with the same row stride and the same
+// repeated padding.  T[row] receives max_b S[i,j,a,b]*X[j,b] for every row, j == i included.
 template <int V, int PASSES, int RB>
-__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int lpr_log2,
-                                              const float *Xs, float *T) {
+__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS,
+                                              int lpr_log2, const float *Xs, float *T) {
   using vec_t = typename VecT<V>::type;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int R2 = R * R;
-  const int cols = R / V;
+  const int cols = RS / V;
   const int lpr = 1 << lpr_log2;
   const int lr = tid & (lpr - 1);
   const int rpp = nt >> lpr_log2;       // rows per step of the whole work-group
@@ -190,60 +201,67 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) coff[p] = min(lr + p * lpr, cols - 1) * V;
 
-  // (j*R, a) of this group's current row, advanced incrementally (no division in the loop)
-  int a = row0 % R, jR = row0 - a;
-  const int dj = rpp / R, da = rpp - dj * R, djR = dj * R;
-  const int jR_last = R2 - R;
+  // (j*RS, a) of this group's current row, advanced incrementally (no division in the loop)
+  int a = row0 % R, jX = (row0 / R) * RS;
+  const int dj = rpp / R, da = rpp - dj * R, djX = dj * RS;
+  const int jX_last = (R - 1) * RS;
 
   for (int row = row0; row < R2; row += rpp * RB) {
     vec_t sv[RB][PASSES];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const int r = min(row + rb * rpp, R2 - 1);
-      const float *src = slab + (unsigned)(r * R);
+      const float *src = slab + (unsigned)(r * RS);
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) sv[rb][p] = stream_load<V>(src + coff[p]);
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const float *xr = Xs + min(jR, jR_last);
+      const float *xr = Xs + min(jX, jX_last);
       float m = -INFINITY;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
-        float s[V], x[V];
-        vec_to_arr<V>(sv[rb][p], s);
+        float sx[V], x[V];
+        vec_to_arr<V>(sv[rb][p], sx);
         vec_to_arr<V>(*reinterpret_cast<const vec_t *>(xr + coff[p]), x);
 #pragma unroll
-        for (int v = 0; v < V; ++v) m = fmaxf(m, s[v] * x[v]);
+        for (int v = 0; v < V; ++v) m = fmaxf(m, sx[v] * x[v]);
       }
       m = group_max(m, lpr_log2);
       const int r_u = row + rb * rpp;
       if (lr == 0 && r_u < R2) T[r_u] = m;
       a += da;
-      jR += djR;
+      jX += djX;
       if (a >= R) {
         a -= R;
-        jR += R;
+        jX += RS;
       }
     }
   }
 }
 
+#ifndef GVAE_STREAM_DEPTH
+#define GVAE_STREAM_DEPTH 4
+#endif
+#ifndef GVAE_STREAM_WAVES
+#define GVAE_STREAM_WAVES 8
+#endif
 // picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
 template <int V>
-__device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R,
+__device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R, int RS,
                                                   const float *Xs, float *T) {
-  const int cols = R / V;
+  const int cols = RS / V;
   int lpr_log2 = 0;
   constexpr int kBase = V == 4 ? 3 : (V == 2 ? 4 : 5);
   while ((1 << lpr_log2) < cols && lpr_log2 < kBase) ++lpr_log2;
   while ((cols + (1 << lpr_log2) - 1) >> lpr_log2 > 4) ++lpr_log2;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
-  if (passes == 1) mpm_iter_body<V, 1, 4>(slab, R, lpr_log2, Xs, T);
-  else if (passes == 2) mpm_iter_body<V, 2, 2>(slab, R, lpr_log2, Xs, T);
-  else if (passes == 3) mpm_iter_body<V, 3, 2>(slab, R, lpr_log2, Xs, T);
-  else mpm_iter_body<V, 4, 1>(slab, R, lpr_log2, Xs, T);
+  constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
+  if (passes == 1) mpm_iter_body<V, 1, D>(slab, R, RS, lpr_log2, Xs, T);
+  else if (passes == 2) mpm_iter_body<V, 2, D / 2>(slab, R, RS, lpr_log2, Xs, T);
+  else if (passes == 3) mpm_iter_body<V, 3, (D + 2) / 3>(slab, R, RS, lpr_log2, Xs, T);
+  else mpm_iter_body<V, 4, D / 4>(slab, R, RS, lpr_log2, Xs, T);
 }
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
@@ -317,12 +335,11 @@ struct MpmQueue {
 #define Q_REMAIN(q) ((q).words + 64)
 #define Q_ERROR(q) ((q).words + 96)
 
-// 64 VGPRs: 8 waves per SIMD, so that eight 256-thread work-groups stream per compute unit
-__global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
+__global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAVES))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
                                   float *__restrict__ Xnew, int64_t strideXnew, float tol,
-                                  int early_stop, int iters, MpmQueue q,
+                                  int early_stop, int iters, int layout, MpmQueue q,
                                   int32_t *__restrict__ iters_done) {
   extern __shared__ float lds[];
   __shared__ float red[16];
@@ -368,21 +385,22 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void mpm_stream_kernel(con
       const int g = item / r_max, i = item - g * r_max;
       const int R = Rarr[g];
       const int R2 = R * R;
-      float *Xs = lds;            // R*R
-      float *T = lds + R2;        // R*R
+      const int RS = s_row_stride(R, layout);
+      float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
+      float *T = lds + R * RS;    // R*R
       float *nsrow = T + R2;      // R
       float *Xg = X + g * strideX;
-      const float *slab = S + S_off[g] + (int64_t)i * R2 * R;
-      for (int e = tid; e < R2; e += nt) {
-        const int r = e / R, c = e - r * R;
-        Xs[e] = Xg[(int64_t)r * ldx + c];
+      const float *slab = S + S_off[g] + (int64_t)i * R2 * RS;
+      for (int e = tid; e < R * RS; e += nt) {
+        const int r = e / RS, c = e - r * RS;
+        Xs[e] = Xg[(int64_t)r * ldx + min(c, R - 1)];
       }
       // S[i,i,a,a], the factor of X[i,a] in the update
-      for (int p = tid; p < R; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * R + p];
+      for (int p = tid; p < R; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
       __syncthreads();
-      if ((R & 3) == 0) mpm_iter_dispatch<4>(slab, R, Xs, T);
-      else if ((R & 1) == 0) mpm_iter_dispatch<2>(slab, R, Xs, T);
-      else mpm_iter_dispatch<1>(slab, R, Xs, T);
+      if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, Xs, T);
+      else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, Xs, T);
+      else mpm_iter_dispatch<1>(slab, R, RS, Xs, T);
       __syncthreads();
       float *Xn = Xnew + g * strideXnew;
       for (int p = tid; p < R; p += nt) {
@@ -390,7 +408,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void mpm_stream_kernel(con
         const float et =
             column_sum([&](int jj) { return jj == i ? 0.0f : T[jj * R + p]; }, p, R);
         // write-through store (no release fence needed for a write-through payload)
-        __hip_atomic_store(&Xn[i * R + p], Xs[i * R + p] * nsrow[p] + et, __ATOMIC_RELAXED,
+        __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsrow[p] + et, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       }
       // publish this row: every storing wave drains its stores, then one lane takes a ticket
@@ -422,10 +440,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(8, 8))) void mpm_stream_kernel(con
         bool isnan_any = false;
         for (int e = tid; e < R2; e += nt) {
           const float v = T[e] / nrm;
-          const float d = fabsf(v - Xs[e]);
+          const int r = e / R, c = e - r * R;
+          const float d = fabsf(v - Xs[r * RS + c]);
           isnan_any |= (d != d);
           dmax = fmaxf(dmax, d);
-          const int r = e / R, c = e - r * R;
           // write-through: the next iteration's consumers run on other compute units
           __hip_atomic_store(&Xg[(int64_t)r * ldx + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -796,18 +814,20 @@ int gvae_node_sim(const float *d_A, const float *d_P, const int32_t *d_R, int n_
 }
 
 int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
-                  int n_graphs, int ld, int64_t stride, int r_max, float *d_S,
+                  int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                   const int64_t *d_S_off, void *stream) {
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_S && d_S_off, GVAE_EINVAL, "edge_sim: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && ld > 0 && r_max > 0 && r_max <= ld && r_max <= 1024, GVAE_EINVAL,
                "edge_sim: bad sizes (n_graphs=%d ld=%d r_max=%d)", n_graphs, ld, r_max);
   GVAE_REQUIRE(((uintptr_t)d_S & 15) == 0, GVAE_EINVAL, "edge_sim: S must be 16-byte aligned");
+  GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
+               "edge_sim: unknown S layout %d", s_layout);
   GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "edge_sim: more than 65535 graphs per call");
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfileScope ps(F_EDGE_SIM, s);
   hipLaunchKernelGGL(edge_sim_kernel, dim3(r_max, n_graphs), dim3(256), 0, s, d_A, d_P, d_NS, d_R,
-                     ld, stride, d_S, d_S_off);
+                     ld, stride, s_layout, d_S, d_S_off);
   return check_launch("edge_sim");
 }
 
@@ -819,16 +839,19 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
          pad256(4LL * n_graphs);
 }
 
-int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R, int n_graphs,
-                    int r_max, float *d_X, int ldx, int64_t strideX, int iters, float tol,
-                    int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                    int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                    float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
   GVAE_REQUIRE(d_S && d_S_off && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "mpm_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "mpm_stream: bad sizes (n_graphs=%d r_max=%d ldx=%d iters=%d)", n_graphs, r_max, ldx,
                iters);
   GVAE_REQUIRE((int64_t)n_graphs * r_max < (1LL << 30), GVAE_ELIMIT, "mpm_stream: too many graphs");
-  const size_t lds = sizeof(float) * (2 * (size_t)r_max * r_max + r_max);
+  GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
+               "mpm_stream: unknown S layout %d", s_layout);
+  const size_t lds =
+      sizeof(float) * ((size_t)r_max * ((r_max + 3) & ~3) + (size_t)r_max * r_max + r_max);
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
   if (n_graphs == 0) return GVAE_OK;
@@ -868,7 +891,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R
   {
     ProfileScope ps(F_MPM_ITER, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
-                       d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, iters, q, d_iters_done);
+                       d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, iters, s_layout, q,
+                       d_iters_done);
   }
   return check_launch("mpm_stream");
 }

@@ -234,8 +234,9 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
                       int r_max, const float *d_eps, const float *d_pos_weight, int train,
                       int matching, int mpm_iters, float tol, int early_stop, float *d_S,
-                      const int64_t *d_S_off, void *d_ws, float *d_out4, int64_t *d_perm,
-                      int32_t *d_iters_done, void *stream) {
+                      const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
+                      void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                      void *stream) {
   GVAE_REQUIRE(d && d_params && d_bn_state && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight &&
                    d_ws && d_out4 && d_perm && d_iters_done,
                GVAE_EINVAL, "step_forward: null pointer");
@@ -245,6 +246,15 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
                "step_forward: unknown matching mode %d", matching);
   GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
                "step_forward: streaming matching needs the S buffer and its offsets");
+  GVAE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || h_chunk_begin), GVAE_EINVAL,
+               "step_forward: bad chunk list");
+  if (n_chunks > 0) {
+    GVAE_REQUIRE(h_chunk_begin[0] == 0 && h_chunk_begin[n_chunks] == n_graphs, GVAE_EINVAL,
+                 "step_forward: chunks must cover graphs 0..%d", n_graphs);
+    for (int c = 0; c < n_chunks; ++c)
+      GVAE_REQUIRE(h_chunk_begin[c] < h_chunk_begin[c + 1], GVAE_EINVAL,
+                   "step_forward: chunk %d is empty or out of order", c);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
   const Workspace w = carve(d, B, (char *)d_ws);
@@ -285,9 +295,19 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
     hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
                        w.X);
     if (matching == GVAE_MATCH_STREAM) {
-      TRY(gvae_edge_sim(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, d_S, d_S_off, s));
-      TRY(gvae_mpm_stream(d_S, d_S_off, d_R, B, r_max, w.X, N, (int64_t)N * N, mpm_iters, tol,
-                          early_stop, d_iters_done, w.mpm_ws, s));
+      // chunk by chunk through the one S buffer (stream order keeps a chunk's matching
+      // ahead of the next chunk's overwrite)
+      const int32_t one_chunk[2] = {0, B};
+      const int32_t *cb = n_chunks > 0 ? h_chunk_begin : one_chunk;
+      const int nc = n_chunks > 0 ? n_chunks : 1;
+      const int64_t NN = (int64_t)N * N;
+      for (int c = 0; c < nc; ++c) {
+        const int g0 = cb[c], nb = cb[c + 1] - cb[c];
+        TRY(gvae_edge_sim(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN, r_max,
+                          GVAE_S_PADDED, d_S, d_S_off + g0, s));
+        TRY(gvae_mpm_stream(d_S, d_S_off + g0, GVAE_S_PADDED, d_R + g0, nb, r_max, w.X + g0 * NN, N,
+                            NN, mpm_iters, tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
+      }
     } else {
       TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
                          mpm_iters, tol, early_stop, d_iters_done, s));

@@ -45,11 +45,12 @@ def lib() -> ctypes.CDLL:
         L.gvae_node_sim.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p,
                                     c_void_p]
         L.gvae_edge_sim.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
-                                    c_int, c_void_p, c_void_p, c_void_p]
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p]
         L.gvae_mpm_stream_ws_bytes.argtypes = [c_int, c_int]
         L.gvae_mpm_stream_ws_bytes.restype = c_int64
-        L.gvae_mpm_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
-                                      c_int64, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]
+        L.gvae_mpm_stream.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                      c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
+                                      c_void_p]
         L.gvae_mpm_fused.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                      c_int, c_void_p, c_int, c_int64, c_int, c_float, c_int,
                                      c_void_p, c_void_p]
@@ -77,7 +78,7 @@ def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- profiling
-FAMILIES = {"edge_sim": 0, "mpm_stream_iter": 1, "mpm_stream_norm": 2, "mpm_fused": 3, "lsap": 4,
+FAMILIES = {"edge_sim": 0, "mpm_stream": 1, "mpm_stream_iter": 1, "mpm_fused": 3, "lsap": 4,
             "node_sim": 5}
 
 
@@ -106,29 +107,59 @@ def node_sim(A: torch.Tensor, P: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
     return NS
 
 
-def s_offsets(R_host, align: int = 4):
-    """Element offsets of each graph's (R,R,R,R) block in a packed S buffer."""
+S_DENSE, S_PADDED = 0, 1
+
+
+def s_block_floats(r: int, layout: int = S_DENSE) -> int:
+    """Floats of one graph's block in the S buffer (a multiple of 4)."""
+    r = int(r)
+    rs = (r + 3) // 4 * 4 if layout == S_PADDED else r
+    return (r ** 3 * rs + 3) // 4 * 4
+
+
+def s_offsets(R_host, layout: int = S_DENSE):
+    """Element offsets of each graph's block in a packed S buffer, and the total."""
     offs, tot = [], 0
     for r in R_host:
         offs.append(tot)
-        tot += (int(r) ** 4 + align - 1) // align * align
+        tot += s_block_floats(r, layout)
     return offs, tot
 
 
-def edge_sim(A, P, NS, R, R_host) -> tuple[torch.Tensor, torch.Tensor]:
+def s_chunks(R_host, budget_floats: int, layout: int = S_PADDED):
+    """Splits the batch into consecutive chunks whose S blocks fit `budget_floats` together.
+    Returns (chunk_begin [n_chunks+1], offsets within the chunk [G], floats of the largest chunk)."""
+    begin, offs, tot, largest = [0], [], 0, 0
+    for g, r in enumerate(R_host):
+        need = s_block_floats(r, layout)
+        if need > budget_floats:
+            raise GvaeHipError(f"one graph of {r} nodes needs {need * 4} bytes of S, over the "
+                               f"budget of {budget_floats * 4} bytes")
+        if tot + need > budget_floats:
+            begin.append(g)
+            tot = 0
+        offs.append(tot)
+        tot += need
+        largest = max(largest, tot)
+    begin.append(len(R_host))
+    return begin, offs, largest
+
+
+def edge_sim(A, P, NS, R, R_host, layout: int = S_DENSE) -> tuple[torch.Tensor, torch.Tensor]:
     _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
     G, N, _ = A.shape
-    offs, tot = s_offsets(R_host)
+    offs, tot = s_offsets(R_host, layout)
     S = torch.empty(max(tot, 4), dtype=torch.float32, device=A.device)
     S_off = torch.tensor(offs, dtype=torch.int64, device=A.device)
     r_max = int(max(R_host)) if len(R_host) else 1
     _check(lib().gvae_edge_sim(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N, N * N,
-                               max(r_max, 1), S.data_ptr(), S_off.data_ptr(), _stream()))
+                               max(r_max, 1), layout, S.data_ptr(), S_off.data_ptr(), _stream()))
     return S, S_off
 
 
 def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
-               early_stop: bool = True, ws: torch.Tensor | None = None) -> torch.Tensor:
+               early_stop: bool = True, ws: torch.Tensor | None = None,
+               layout: int = S_DENSE) -> torch.Tensor:
     """X: (G, N, N) fp32, X0 in / result out (leading R x R blocks).  Returns iters_done (G,) int32."""
     _dev(S, torch.float32), _dev(S_off, torch.int64), _dev(R, torch.int32), _dev(X, torch.float32)
     G, N, _ = X.shape
@@ -136,7 +167,7 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=X.device)
     done = torch.empty(G, dtype=torch.int32, device=X.device)
-    _check(lib().gvae_mpm_stream(S.data_ptr(), S_off.data_ptr(), R.data_ptr(), G, r_max,
+    _check(lib().gvae_mpm_stream(S.data_ptr(), S_off.data_ptr(), layout, R.data_ptr(), G, r_max,
                                  X.data_ptr(), N, N * N, iters, tol, int(early_stop),
                                  done.data_ptr(), ws.data_ptr(), _stream()))
     return done

@@ -45,8 +45,8 @@ def _bind():
     L.gvae_step_ws_bytes.restype = c_int64
     L.gvae_step_forward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p]
+                                    c_float, c_int, c_void_p, c_void_p, POINTER(c_int32), c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.gvae_step_backward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p]
@@ -77,7 +77,8 @@ class StepEngine:
     size; scratch is grown on demand and reused."""
 
     def __init__(self, F: int, H: int, Z: int, N: int, device, matching: str = "auto",
-                 mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True):
+                 mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
+                 s_budget_bytes: int | None = None):
         self.L = _bind()
         self.dims = Dims(F, H, Z, N)
         self.F, self.H, self.Z, self.N = F, H, Z, N
@@ -90,9 +91,15 @@ class StepEngine:
         self.mpm_iters, self.tol, self.early_stop = int(mpm_iters), float(tol), bool(early_stop)
         self._ws = None
         self._ws_graphs = 0
+        # the streamed matching keeps the similarity tensor of as many graphs as fit this many
+        # bytes and walks the batch in chunks (default: a third of the device's memory)
+        if s_budget_bytes is None:
+            s_budget_bytes = torch.cuda.get_device_properties(self.device).total_memory // 3
+        self.s_budget_bytes = int(s_budget_bytes)
         self._S = None
         self._S_off = None
         self._S_key = None
+        self._S_chunks = None
         self._adam_ws = torch.empty(self.L.gvae_adam_ws_bytes(), dtype=torch.uint8, device=self.device)
         self.out4 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.perm = None
@@ -119,10 +126,12 @@ class StepEngine:
         key = tuple(r_host)
         if key == self._S_key:
             return
-        offs, tot = _hip.s_offsets(r_host)
-        if self._S is None or self._S.numel() < tot:
-            self._S = torch.empty(max(tot, 4), dtype=torch.float32, device=self.device)
+        begin, offs, largest = _hip.s_chunks(r_host, self.s_budget_bytes // 4)
+        if self._S is None or self._S.numel() < largest:
+            self._S = None  # release before growing
+            self._S = torch.empty(max(largest, 4), dtype=torch.float32, device=self.device)
         self._S_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        self._S_chunks = (c_int32 * len(begin))(*begin)
         self._S_key = key
 
     def _check_batch(self, b: DenseGraphBatch) -> None:
@@ -151,15 +160,17 @@ class StepEngine:
             raise _hip.GvaeHipError(f"eps must be ({B}, {self.Z})")
         r_max = max(batch.r_host)
         mode = self.resolve_matching(r_max)
-        S_ptr, Soff_ptr = None, None
+        S_ptr, Soff_ptr, chunks, n_chunks = None, None, None, 0
         if mode == MATCH_STREAM:
             self._ensure_S(batch.r_host)
             S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()
+            chunks, n_chunks = self._S_chunks, len(self._S_chunks) - 1
         _hip._check(self.L.gvae_step_forward(
             ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
             batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B, r_max,
             eps.data_ptr(), pos_weight.data_ptr(), int(train), mode, self.mpm_iters, self.tol,
-            int(self.early_stop), S_ptr, Soff_ptr, self._ws.data_ptr(), self.out4.data_ptr(),
+            int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
+            self.out4.data_ptr(),
             self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
         self.generation += 1
         self._fwd_batch = (batch, eps)

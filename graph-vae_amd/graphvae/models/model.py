@@ -107,8 +107,11 @@ class _StepFunction(torch.autograd.Function):
 class GraphVAE(nn.Module):
     def __init__(self, in_dim: int, hid_dim: int, z_dim: int, max_nodes: int, *, pool: str = "sum",
                  matching: str = "auto", mpm_iters: int = 50, mpm_tol: float = 1e-4,
-                 mpm_early_stop: bool = True) -> None:
+                 mpm_early_stop: bool = True, s_budget_bytes: int | None = None) -> None:
         super().__init__()
+        # bytes of HBM the streamed matching may use for the similarity tensor at a time
+        # (None: a third of the device); larger batches are matched in chunks
+        self.s_budget_bytes = s_budget_bytes
         self.in_dim, self.hid_dim, self.z_dim = int(in_dim), int(hid_dim), int(z_dim)
         self.max_nodes = int(max_nodes)
         self.pool = pool
@@ -221,7 +224,8 @@ class GraphVAE(nn.Module):
         if self._engine is None:
             self._engine = StepEngine(self.in_dim, self.hid_dim, self.z_dim, self.max_nodes, dev,
                                       matching=self.matching, mpm_iters=self.mpm_iters,
-                                      tol=self.mpm_tol, early_stop=self.mpm_early_stop)
+                                      tol=self.mpm_tol, early_stop=self.mpm_early_stop,
+                                      s_budget_bytes=self.s_budget_bytes)
         return self._engine
 
     # ------------------------------------------------------------------ dataset statistics

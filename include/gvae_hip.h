@@ -44,8 +44,8 @@ const char *gvae_last_error(void);
  * gvae_profile_read synchronises the recorded events (host blocks).            */
 int gvae_profile_enable(int on);
 int gvae_profile_reset(void);
-/* family: 0 = edge_sim, 1 = mpm_stream iteration, 2 = mpm_stream normalise,
- *         3 = mpm_fused, 4 = lsap, 5 = node_sim                                 */
+/* family: 0 = edge_sim, 1 = mpm_stream, 2 = unused, 3 = mpm_fused, 4 = lsap,
+ *         5 = node_sim                                                          */
 int gvae_profile_read(int family, double *total_ms, int64_t *launches);
 
 /* ---------------------------------------------------------------------------
@@ -56,29 +56,39 @@ int gvae_profile_read(int family, double *total_ms, int64_t *launches);
 int gvae_node_sim(const float *d_A, const float *d_P, const int32_t *d_R, int n_graphs,
                   int ld, int64_t stride, float *d_NS, void *stream);
 
+/* Layouts of a graph's block in the S buffer.  DENSE is the reference's (R,R,R,R)
+ * tensor.  PADDED stores every row S[i,j,a,:] in RS = 4*ceil(R/4) floats (the tail
+ * repeats the row's last element, which cannot change a row maximum), so that all
+ * rows are 16-byte aligned whatever R is; the block then holds R*R*R*RS floats. */
+#define GVAE_S_DENSE 0
+#define GVAE_S_PADDED 1
+
 /* ---------------------------------------------------------------------------
  * Edge-similarity tensor, materialised.  Replaces GraphVAE._edge_sim_tensor,
  * graphvae/models/model.py:171-216.  Graph g's tensor is written contiguously as
- * (R,R,R,R) fp32, index order (i,j,a,b), at d_S + d_S_off[g] (element offsets;
- * each must be a multiple of 4).  d_NS comes from gvae_node_sim.  r_max >= max R.
+ * (R,R,R,R) fp32 (rows of RS floats for GVAE_S_PADDED), index order (i,j,a,b), at
+ * d_S + d_S_off[g] (element offsets; each must be a multiple of 4).  d_NS comes
+ * from gvae_node_sim.  r_max >= max R.
  */
 int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
-                  int n_graphs, int ld, int64_t stride, int r_max, float *d_S,
+                  int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                   const int64_t *d_S_off, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Max-pool matching on a materialised S (streams S from HBM once per iteration).
  * Replaces GraphVAE._mpm, graphvae/models/model.py:247-276.  d_X holds X0 on
  * entry and the result on exit (layout (n_graphs, ldx, ldx), stride strideX).
- * The per-iteration host sync of the reference (model.py:273) is replaced by a
- * per-graph device flag: a converged graph's work-groups exit at once.
+ * The whole batch runs in one launch: the per-iteration host sync of the reference
+ * (model.py:273) is replaced by a device-side work queue in which every graph
+ * advances on its own and leaves as soon as it has converged.
+ *   s_layout      GVAE_S_DENSE or GVAE_S_PADDED, as the blocks at d_S_off were written
  *   d_iters_done  int32[n_graphs] out: iterations executed per graph
  *   d_ws          workspace, gvae_mpm_stream_ws_bytes(n_graphs, ldx) bytes
  */
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx);
-int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, const int32_t *d_R, int n_graphs,
-                    int r_max, float *d_X, int ldx, int64_t strideX, int iters, float tol,
-                    int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
+int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                    int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                    float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Max-pool matching without S: same recurrence and same bits as
@@ -151,8 +161,13 @@ int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs);
  *   d_R          real nodes per graph;  r_max >= max R (host value)
  *   d_eps        (n_graphs, Z) standard-normal draws for the reparameterisation
  *   d_pos_weight 1 float: the pos_weight_global buffer
- *   matching     GVAE_MATCH_*;  STREAM needs d_S (sum of R^4 floats, 16-byte aligned
- *                blocks) and d_S_off; both may be NULL otherwise
+ *   matching     GVAE_MATCH_*;  STREAM needs d_S and d_S_off (both may be NULL otherwise).
+ *                S is kept in the GVAE_S_PADDED layout and may be smaller than the batch's
+ *                whole tensor: the graphs are matched in n_chunks consecutive chunks,
+ *                chunk c = graphs [h_chunk_begin[c], h_chunk_begin[c+1]), all reusing d_S;
+ *                d_S_off[g] is graph g's offset from the start of d_S within its chunk
+ *                (so it restarts at 0 at every chunk).  h_chunk_begin is a HOST array of
+ *                n_chunks+1 entries; NULL with n_chunks = 0 means one chunk.
  *   d_out4       [rec, kl, max_logit, logvar_max]   (loss = rec + kl)
  *   d_perm       (n_graphs, N) int64 perm_full per graph;  d_iters_done MPM iterations
  */
@@ -160,8 +175,9 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
                       int r_max, const float *d_eps, const float *d_pos_weight, int train,
                       int matching, int mpm_iters, float tol, int early_stop, float *d_S,
-                      const int64_t *d_S_off, void *d_ws, float *d_out4, int64_t *d_perm,
-                      int32_t *d_iters_done, void *stream);
+                      const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
+                      void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                      void *stream);
 
 /* Backward of  c_rec*up[0]*rec + c_kl*up[1]*kl  with respect to every parameter
  * (what loss.backward() does in graphvae/train/train_ddp.py:283-291, where

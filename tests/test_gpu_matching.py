@@ -161,6 +161,42 @@ def test_random_ragged_batch_vs_oracle(hip):
         assert np.array_equal(o["perm"][k, :R], ora.assign_perm(X)), R
 
 
+def test_padded_layout_equals_dense(hip):
+    """The padded S layout (rows of 4*ceil(R/4) floats, last element repeated) holds the dense
+    tensor's values in its leading R columns and gives the same X and iteration counts, bit
+    for bit, for every residue of R mod 4."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    Rh = [2, 3, 5, 6, 7, 9, 13, 18, 21, 27, 30, 31, 33, 34, 35, 36]
+    N = max(Rh)
+    As, Ps = [], []
+    for R in Rh:
+        up = np.triu((rng.random((R, R)) < 0.35).astype(np.float32), 1)
+        As.append(up + up.T + np.eye(R, dtype=np.float32))
+        lg = np.triu(rng.normal(0, 1.5, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    A = torch.from_numpy(_pack(As, N)).to(dev)
+    P = torch.from_numpy(_pack(Ps, N)).to(dev)
+    R = torch.tensor(Rh, dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    Sd, offd = hip.edge_sim(A, P, NS, R, Rh, hip.S_DENSE)
+    Sp, offp = hip.edge_sim(A, P, NS, R, Rh, hip.S_PADDED)
+    Xd, Xp = hip.x0_uniform(Rh, N, dev), hip.x0_uniform(Rh, N, dev)
+    dd = hip.mpm_stream(Sd, offd, R, N, Xd, 50, 1e-4, True, layout=hip.S_DENSE)
+    dp = hip.mpm_stream(Sp, offp, R, N, Xp, 50, 1e-4, True, layout=hip.S_PADDED)
+    assert torch.equal(Xd, Xp) and torch.equal(dd, dp)
+    Sd_h, Sp_h = Sd.cpu().numpy(), Sp.cpu().numpy()
+    for k, r in enumerate(Rh):
+        rs = (r + 3) // 4 * 4
+        dense = Sd_h[int(offd[k]):int(offd[k]) + r ** 4].reshape(r, r, r, r)
+        padded = Sp_h[int(offp[k]):int(offp[k]) + r ** 3 * rs].reshape(r, r, r, rs)
+        assert np.array_equal(padded[..., :r], dense), r
+        for extra in range(r, rs):
+            assert np.array_equal(padded[..., extra], dense[..., r - 1]), r
+        Xo, done = ora.mpm(dense, ora.x0_uniform(r))
+        assert int(dp[k]) == done and np.array_equal(Xp[k, :r, :r].cpu().numpy(), Xo), r
+
+
 def test_mpm_stream_arbitrary_S_vs_oracle(hip):
     """_mpm's public contract takes any S (reference model_legacy2.py:670-708 feeds
     uniform random tensors): compare with the oracle on such inputs."""

@@ -197,6 +197,34 @@ def test_default_sizes_vs_cpu_restatement(feature_type, N, B, kind):
     check_grads(got, ref_g, truth64(G), TOL)
 
 
+def test_chunked_streamed_matching_equals_one_chunk():
+    """A similarity-tensor budget smaller than the batch's tensor makes the step walk the
+    batch in chunks through one S buffer: same losses, permutations and gradients, bit for
+    bit, as with everything resident."""
+    from graphvae import _hip
+    from graphvae.data import synthetic_batch
+    from graphvae.models import GraphVAE
+    N, B = 24, 12
+    hb = synthetic_batch("enzymes", B, N, "deg", seed=11)
+    eps = torch.randn(B, 16, generator=torch.Generator().manual_seed(3))
+    results = []
+    for budget in (None, 3 * _hip.s_block_floats(N, _hip.S_PADDED) * 4):
+        torch.manual_seed(4)
+        model = GraphVAE(1, 32, 16, N, matching="stream", s_budget_bytes=budget)
+        model.precompute_dataset_rho([hb])
+        model = model.to(DEV).train()
+        out = model.forward_with_eps(hb.to(DEV), eps.to(DEV))
+        out["loss"].backward()
+        n_chunks = len(model._engine._S_chunks) - 1
+        grads = torch.cat([p.grad.reshape(-1) for p in model._named_param_list()])
+        results.append((n_chunks, out["rec"].item(), out["kl"].item(),
+                        model.last_permutations().clone(), model._engine.iters_done.clone(), grads))
+    (n1, rec1, kl1, perm1, it1, g1), (n2, rec2, kl2, perm2, it2, g2) = results
+    assert n1 == 1 and n2 >= 3
+    assert rec1 == rec2 and kl1 == kl2
+    assert torch.equal(perm1, perm2) and torch.equal(it1, it2) and torch.equal(g1, g2)
+
+
 def test_forward_requires_rho_and_gpu():
     from graphvae.data import synthetic_batch
     from graphvae.models import GraphVAE

@@ -227,3 +227,24 @@ def test_forward_guards_without_gpu():
             m(b)
         with pytest.raises(GvaeHipError):
             m._edge_sim_tensor(torch.eye(3), torch.eye(3))
+
+
+def test_s_chunks_cover_the_batch_within_budget():
+    """Chunk boundaries of the streamed matching: consecutive, covering, every chunk within
+    the budget, offsets restarting at each chunk; a graph over the budget is an error."""
+    from graphvae import _hip
+    Rh = [5, 12, 12, 7, 3, 12, 9, 9, 2]
+    blk = [_hip.s_block_floats(r, _hip.S_PADDED) for r in Rh]
+    assert all(b % 4 == 0 for b in blk) and blk[0] == 5 ** 3 * 8
+    budget = 2 * blk[1] + 100
+    begin, offs, largest = _hip.s_chunks(Rh, budget)
+    assert begin[0] == 0 and begin[-1] == len(Rh) and sorted(set(begin)) == begin
+    for c in range(len(begin) - 1):
+        tot = 0
+        for g in range(begin[c], begin[c + 1]):
+            assert offs[g] == tot
+            tot += blk[g]
+        assert tot <= budget and tot <= largest
+    assert _hip.s_chunks(Rh, 10 ** 12)[0] == [0, len(Rh)]
+    with pytest.raises(_hip.GvaeHipError):
+        _hip.s_chunks(Rh, blk[1] - 4)
