@@ -787,6 +787,14 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
   if (tid == 0) iters_done[g] = done;
 }
 
+// after the persistent kernel: a queue fault (a bounded spin ran out) turns every graph's
+// iteration count into -(fault code), so that the caller can see that X is not to be trusted
+__global__ void mpm_queue_check_kernel(MpmQueue q, int n_graphs, int32_t *__restrict__ iters_done) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int err = *Q_ERROR(q);
+  if (t < n_graphs && err != 0) iters_done[t] = -err;
+}
+
 __global__ void zero_i32_kernel(int32_t *a, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) a[t] = 0;
@@ -894,6 +902,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                        d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, iters, s_layout, q,
                        d_iters_done);
   }
+  hipLaunchKernelGGL(mpm_queue_check_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, q,
+                     n_graphs, d_iters_done);
   return check_launch("mpm_stream");
 }
 

@@ -106,6 +106,7 @@ class StepEngine:
         self.iters_done = None
         self.generation = 0
         self._fwd_batch = None
+        self.last_mode = MATCH_NONE
 
     # ------------------------------------------------------------------ helpers
     def _ensure(self, B: int) -> None:
@@ -208,6 +209,17 @@ class StepEngine:
             float(clip_max), float(lr), float(betas[0]), float(betas[1]), float(eps),
             float(weight_decay), int(step), self._adam_ws.data_ptr(),
             norm_out.data_ptr() if norm_out is not None else None, _hip._stream()))
+
+    def check_matching(self) -> None:
+        """Synchronises and raises if the last forward's matching reported a fault (a negative
+        iteration count from the streamed MPM's work queue, or a non-finite assignment cost)."""
+        if self.iters_done is None:
+            return
+        if bool((self.iters_done < 0).any()):
+            raise _hip.GvaeHipError("streamed MPM: the device work queue faulted; X is invalid")
+        B = self.iters_done.shape[0]
+        if self.last_mode != MATCH_NONE and bool((self.debug_tensor("status", B) != 0).any()):
+            raise _hip.GvaeHipError("assignment: non-finite or infeasible cost matrix")
 
     # ------------------------------------------------------------------ inspection (tests)
     _DEBUG = {"vec_logits": 0, "node_logits": 1, "P": 2, "X": 3, "mu": 4, "logvar_raw": 5, "rec_i": 6,

@@ -302,6 +302,8 @@ def _ddp_worker(rank: int, world: int, args) -> None:
                     dbg.log("debug/grad_norm", step_fn.grad_norm.item())
             dbg.next()
             global_step += 1
+        if getattr(model, "_engine", None) is not None:
+            model._engine.check_matching()                  # once per epoch: faults of the matching kernels
         tot_tr = acc.clone()
         if world > 1:
             dist.all_reduce(tot_tr, op=dist.ReduceOp.SUM)

@@ -82,7 +82,8 @@ int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const i
  * (model.py:273) is replaced by a device-side work queue in which every graph
  * advances on its own and leaves as soon as it has converged.
  *   s_layout      GVAE_S_DENSE or GVAE_S_PADDED, as the blocks at d_S_off were written
- *   d_iters_done  int32[n_graphs] out: iterations executed per graph
+ *   d_iters_done  int32[n_graphs] out: iterations executed per graph; negative for every
+ *                 graph if the work queue faulted (a bounded wait ran out: X is invalid)
  *   d_ws          workspace, gvae_mpm_stream_ws_bytes(n_graphs, ldx) bytes
  */
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx);
