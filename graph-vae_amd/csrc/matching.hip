@@ -335,6 +335,15 @@ struct MpmQueue {
 #define Q_REMAIN(q) ((q).words + 64)
 #define Q_ERROR(q) ((q).words + 96)
 
+// Diagnostic build (-DGVAE_STREAM_STAMPS): lane 0 of a few work-groups prints the cycles its
+// items spent per phase.
+#ifdef GVAE_STREAM_STAMPS
+#define SSTAMP(k) do { if (tid == 0) { const long long t_ = __builtin_readcyclecounter(); \
+                       ss_acc[k] += t_ - ss_last; ss_last = t_; } } while (0)
+#else
+#define SSTAMP(k) do {} while (0)
+#endif
+
 __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAVES))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
@@ -346,7 +355,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
   __shared__ float s_nrm;
   __shared__ int s_item, s_last, s_cont, s_base;
   const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef GVAE_STREAM_STAMPS
+  long long ss_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long ss_last = __builtin_readcyclecounter();
+  int ss_items = 0, ss_lasts = 0;
+#endif
   for (;;) {
+    SSTAMP(9);
     // ---- draw a ticket and wait for its granule (one lane)
     if (tid == 0) {
       const unsigned ticket = (unsigned)__hip_atomic_fetch_add(Q_HEAD(q), 1, __ATOMIC_RELAXED,
@@ -381,6 +396,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
     __syncthreads();
     const int item = s_item;
     if (item == -2) break;
+    SSTAMP(0);
+#ifdef GVAE_STREAM_STAMPS
+    ++ss_items;
+#endif
     if ((unsigned)item != MPM_NULL_ITEM) {
       const int g = item / r_max, i = item - g * r_max;
       const int R = Rarr[g];
@@ -398,10 +417,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       // S[i,i,a,a], the factor of X[i,a] in the update
       for (int p = tid; p < R; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
       __syncthreads();
+      SSTAMP(1);
       if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, Xs, T);
       else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, Xs, T);
       else mpm_iter_dispatch<1>(slab, R, RS, Xs, T);
       __syncthreads();
+      SSTAMP(2);
       float *Xn = Xnew + g * strideXnew;
       for (int p = tid; p < R; p += nt) {
         // the row j == i does not take part in the sum: an exact +0 at its position
@@ -414,6 +435,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       // publish this row: every storing wave drains its stores, then one lane takes a ticket
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      SSTAMP(3);
       if (tid == 0) {
         const int ticket =
             __hip_atomic_fetch_add(&q.arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -423,10 +445,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      SSTAMP(4);
       if (s_last) {
+#ifdef GVAE_STREAM_STAMPS
+        ++ss_lasts;
+#endif
         // ---- last arriver: normalise the graph
         for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
         __syncthreads();
+        SSTAMP(5);
         const int n8 = R2 & ~7;
         if (tid < 64) {
           float acc = 0.f;
@@ -435,6 +462,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           if (tid == 0) s_nrm = nrm;
         }
         __syncthreads();
+        SSTAMP(6);
         const float nrm = s_nrm;
         float dmax = 0.f;
         bool isnan_any = false;
@@ -465,6 +493,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         // X, the iteration count and the reset counter are drained before anything is pushed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        SSTAMP(7);
         if (s_cont) {
           const unsigned base = (unsigned)s_base;
           for (int p = tid; p < R; p += nt) {
@@ -490,7 +519,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       }
     }
     __syncthreads();  // s_item and the LDS buffers are free again
+    SSTAMP(8);
   }
+#ifdef GVAE_STREAM_STAMPS
+  if (tid == 0 && ss_items > 0 && (blockIdx.x & 255) == 0)
+    printf("stream stamps wg %d: items %d lasts %d | wait %lld  xload %lld  stream %lld  colsum+store %lld  "
+           "arrive %lld | last: reload %lld  norm %lld  divide+store %lld  push %lld | loop %lld\n",
+           blockIdx.x, ss_items, ss_lasts, ss_acc[0], ss_acc[1], ss_acc[2], ss_acc[3], ss_acc[4],
+           ss_acc[5], ss_acc[6], ss_acc[7], ss_acc[8], ss_acc[9]);
+#endif
 }
 
 // first generation of the ring: one slot per (graph, i < r_max); rows beyond R are null items
@@ -885,7 +922,9 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                "mpm_stream: memset failed");
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(ceil_div(n_items, 256)), dim3(256), 0, s, q, d_R,
                      n_graphs, r_max, d_iters_done);
-  const int nt = r_max > 64 ? 1024 : 256;
+  // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
+  // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
+  const int nt = r_max >= 48 ? 1024 : 256;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -894,7 +933,7 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   }
   // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
   // others leave, which only happens once every graph is finished, and then leave at once
-  const int max_blocks = nt == 256 ? 2048 : 512;
+  const int max_blocks = 2048 * 256 / nt;
   const int blocks = n_items < max_blocks ? n_items : max_blocks;
   {
     ProfileScope ps(F_MPM_ITER, s);
