@@ -12,58 +12,188 @@
 //     order that is unassigned if there is one, otherwise the first one in list order.
 // The column scan (the O(n) inner loop) is spread over the 64 lanes; the selection
 // rule above is evaluated with wave-wide min/max reductions, which is equivalent to
-// the sequential scan.  Dual variables, distances and the path live in LDS together
-// with the fp32 matrix itself.
+// the sequential scan.  Dual variables, distances, the path and the list order live in
+// registers; only the fp32 matrix itself is in LDS.
 #include "gvae_common.h"
 
 namespace gvae {
 
 // Wave-wide reductions on the data-parallel-primitive path (no LDS traffic): an xor butterfly
-// inside each row of 16 lanes (quad permutes, then half-row and row mirrors), then the four
-// row results are combined through scalar lane reads.  Every lane ends up with the result.
-template <int CTRL>
+// inside each row of 16 lanes (quad permutes, then half-row and row mirrors), then the row
+// results are folded upwards with the two row-broadcast moves and read from lane 63.
+template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi2, lo2);
 }
-__device__ __forceinline__ double min_f64(double a, double b) { return b < a ? b : a; }
 __device__ __forceinline__ double read_lane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// one v_min_f64 (fmin() would add two canonicalising instructions per call; no NaNs reach
+// these reductions: costs are checked beforehand)
+__device__ __forceinline__ double min1_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double wave_min_f64(double v) {
-  v = min_f64(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = min_f64(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror
-  v = min_f64(v, dpp_f64<0x140>(v));  // row_mirror
-  return min_f64(min_f64(read_lane_f64(v, 0), read_lane_f64(v, 16)),
-                 min_f64(read_lane_f64(v, 32), read_lane_f64(v, 48)));
+  v = min1_f64(v, dpp_f64<0xB1>(v));        // quad_perm [1,0,3,2]
+  v = min1_f64(v, dpp_f64<0x4E>(v));        // quad_perm [2,3,0,1]
+  v = min1_f64(v, dpp_f64<0x141>(v));       // row_half_mirror
+  v = min1_f64(v, dpp_f64<0x140>(v));       // row_mirror: every lane of a row holds the row's minimum
+  v = min1_f64(v, dpp_f64<0x142, 0xa>(v));  // row_bcast15: rows 1 and 3 take in rows 0 and 2
+  v = min1_f64(v, dpp_f64<0x143, 0xc>(v));  // row_bcast31: rows 2 and 3 take in row 1
+  return read_lane_f64(v, 63);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+  v = max(v, dpp_i32<0xB1>(v));
+  v = max(v, dpp_i32<0x4E>(v));
+  v = max(v, dpp_i32<0x141>(v));
+  v = max(v, dpp_i32<0x140>(v));
+  v = max(v, dpp_i32<0x142, 0xa>(v));
+  v = max(v, dpp_i32<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-// LDS layout per graph (n = r_max rounded up to even):
-//   double u[n], v[n], spc[n];  int path[n], col4row[n], row4col[n], remaining[n];
-//   uchar SR[n], SC[n] (as ints for simplicity);  float cost[n*n] (= X, negated on read)
+// value of a per-lane array element held by lane (idx & 63), chunk (idx >> 6); idx is uniform
+template <int NCH>
+__device__ __forceinline__ int pick_i32(const int (&a)[NCH], int idx) {
+  const int l = idx & 63;
+  int r = __builtin_amdgcn_readlane(a[0], l);
+  if constexpr (NCH == 2) {
+    if (idx >= 64) r = __builtin_amdgcn_readlane(a[1], l);
+  }
+  return r;
+}
+template <int NCH>
+__device__ __forceinline__ double pick_f64(const double (&a)[NCH], int idx) {
+  const int l = idx & 63;
+  double r = read_lane_f64(a[0], l);
+  if constexpr (NCH == 2) {
+    if (idx >= 64) r = read_lane_f64(a[1], l);
+  }
+  return r;
+}
+
+// One wavefront per graph, the whole solver state in registers: lane l owns columns and rows
+// l (and l + 64 when NCH == 2).  Column state: dual v, tentative distance spc, predecessor
+// path, row4col, and pos = the column's position in the list of unscanned columns (-1 once
+// scanned).  Row state: dual u, col4row, the scanned-row flag.  Only the cost matrix (= X,
+// negated on read) sits in LDS.  The wave-uniform scalars (current row i, the chosen column,
+// the sink) move between lanes with readlane / DPP; there is no barrier in the solver.
+//
+// The sequential rule "among the columns at the minimum distance, the last unassigned one in
+// list order, else the first one in list order" becomes one integer maximum over the keys
+//   unassigned: 0x10000 + pos      assigned: 0xFFFF - pos      (list positions are unique)
+template <int NCH>
+__device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, int (&col4row)[NCH]) {
+  double u[NCH], v[NCH], spc[NCH];
+  int path[NCH], row4col[NCH], pos[NCH];
+  bool SR[NCH], SC[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u[c] = 0.0; v[c] = 0.0; spc[c] = INFINITY;
+    path[c] = -1; row4col[c] = -1; col4row[c] = -1; pos[c] = -1;
+    SR[c] = false; SC[c] = false;
+  }
+  for (int cur = 0; cur < n; ++cur) {
+    double minVal = 0.0;
+    int i = cur, num_remaining = n, sink = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 64 + lane;
+      pos[c] = col < n ? n - 1 - col : -1;   // the list starts as n-1, n-2, ..., 0
+      SR[c] = false; SC[c] = false;
+      spc[c] = INFINITY;
+    }
+    while (sink == -1) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (c * 64 + lane == i) SR[c] = true;
+      const double ui = pick_f64<NCH>(u, i);
+      const float *crow = cost + i * n;
+      double lowest = INFINITY;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (pos[c] >= 0) {
+          const double r = minVal + (double)(-crow[c * 64 + lane]) - ui - v[c];
+          if (r < spc[c]) { path[c] = i; spc[c] = r; }
+          lowest = spc[c] < lowest ? spc[c] : lowest;
+        }
+      }
+      lowest = wave_min_f64(lowest);
+      if (lowest == INFINITY) return 1;      // infeasible
+      int key = -1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (pos[c] >= 0 && spc[c] == lowest) {
+          const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
+          key = max(key, k);
+        }
+      }
+      const int best = wave_max_i32(key);
+      const int L = __ffsll((long long)__ballot(key == best)) - 1;
+      const int j = (best & 1) * 64 + L;
+      minVal = lowest;
+      const int rj = pick_i32<NCH>(row4col, j);
+      const int pj = pick_i32<NCH>(pos, j);
+      if (rj == -1) sink = j; else i = rj;
+      // remove j from the list: the list's last entry moves into j's place
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (pos[c] == num_remaining - 1) pos[c] = pj;
+        if (c * 64 + lane == j) { pos[c] = -1; SC[c] = true; }
+      }
+      --num_remaining;
+    }
+    // dual updates
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int row = c * 64 + lane;
+      // distance of the column this row is assigned to (gathered from its owner lane)
+      const int cr = col4row[c] < 0 ? 0 : col4row[c];
+      double s_cr = __shfl(spc[0], cr & 63, 64);
+      if constexpr (NCH == 2) {
+        const double s1 = __shfl(spc[1], cr & 63, 64);
+        if (cr >= 64) s_cr = s1;
+      }
+      if (row == cur) u[c] += minVal;
+      else if (SR[c]) u[c] += minVal - s_cr;
+      if (SC[c]) v[c] -= minVal - spc[c];
+    }
+    // augment along the path (wave-uniform walk)
+    int j = sink;
+    for (;;) {
+      const int r = pick_i32<NCH>(path, j);
+      const int t = pick_i32<NCH>(col4row, r);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c * 64 + lane == j) row4col[c] = r;
+        if (c * 64 + lane == r) col4row[c] = j;
+      }
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  return 0;
+}
+
+// LDS: float cost[n*n] (= X)
 __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ X, int ldx,
                                                   int64_t strideX,
                                                   const int32_t *__restrict__ Rarr, int r_max,
                                                   int64_t *__restrict__ perm, int n_perm,
                                                   int32_t *__restrict__ status) {
-  extern __shared__ double lds_d[];
+  extern __shared__ float cost[];
   const int g = blockIdx.x, lane = threadIdx.x;
   const int n = Rarr[g];
-  const int np = (r_max + 1) & ~1;
-  double *u = lds_d, *v = u + np, *spc = v + np;
-  int *path = reinterpret_cast<int *>(spc + np);
-  int *col4row = path + np, *row4col = col4row + np, *remaining = row4col + np;
-  int *SR = remaining + np, *SC = SR + np;
-  float *cost = reinterpret_cast<float *>(SC + np);
-
   int64_t *pg = perm + (int64_t)g * n_perm;
   for (int k = lane; k < n_perm; k += 64) pg[k] = k;
   if (n <= 0) {
@@ -78,105 +208,26 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ X, i
     cost[e] = x;
     bad |= (x != x) || (x == INFINITY);  // cost = -x: NaN or -inf is invalid
   }
-  for (int k = lane; k < n; k += 64) {
-    u[k] = 0.0; v[k] = 0.0; path[k] = -1; col4row[k] = -1; row4col[k] = -1;
-  }
   bad = wave_max_i32(bad);
   if (bad) {
     if (lane == 0) status[g] = 1;
     return;
   }
   __syncthreads();
-
-  int fail = 0;
-  for (int cur = 0; cur < n && !fail; ++cur) {
-    double minVal = 0.0;
-    int i = cur, num_remaining = n, sink = -1;
-    for (int k = lane; k < n; k += 64) {
-      remaining[k] = n - k - 1;
-      SR[k] = 0; SC[k] = 0;
-      spc[k] = INFINITY;
+  int fail;
+  if (n <= 64) {
+    int col4row[1];
+    fail = lsap_solve<1>(cost, n, lane, col4row);
+    if (!fail && lane < n) pg[col4row[0]] = lane;            // perm[col4row[i]] = i
+  } else {
+    int col4row[2];
+    fail = lsap_solve<2>(cost, n, lane, col4row);
+    if (!fail) {
+      pg[col4row[0]] = lane;
+      if (64 + lane < n) pg[col4row[1]] = 64 + lane;
     }
-    __syncthreads();
-    while (sink == -1) {
-      if (lane == 0) SR[i] = 1;
-      const double ui = u[i];
-      const float *crow = cost + i * n;
-      // pass over the unscanned columns, two chunks of 64 lanes (n <= 128)
-      double sj[2];
-      int free_col[2];
-      double lowest = INFINITY;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int it = c * 64 + lane;
-        sj[c] = INFINITY;
-        free_col[c] = 0;
-        if (it < num_remaining) {
-          const int j = remaining[it];
-          const double r = minVal + (double)(-crow[j]) - ui - v[j];
-          double cur_s = spc[j];
-          if (r < cur_s) { path[j] = i; spc[j] = r; cur_s = r; }
-          sj[c] = cur_s;
-          free_col[c] = row4col[j] == -1;
-          lowest = cur_s < lowest ? cur_s : lowest;
-        }
-      }
-      lowest = wave_min_f64(lowest);
-      if (lowest == INFINITY) { fail = 1; break; }
-      // among the columns at the minimum: the last unassigned one in list order if there is
-      // one, else the first one in list order (what the sequential scan ends up with)
-      int last_free = -1, first_any = 0x7fffffff;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bool at_min = (c * 64 + lane < num_remaining) && sj[c] == lowest;
-        const unsigned long long bm = __ballot(at_min);
-        const unsigned long long bf = __ballot(at_min && free_col[c]);
-        if (bm != 0ull && first_any == 0x7fffffff) first_any = c * 64 + __ffsll((long long)bm) - 1;
-        if (bf != 0ull) last_free = c * 64 + 63 - __clzll((long long)bf);
-      }
-      const int index = last_free >= 0 ? last_free : first_any;
-      minVal = lowest;
-      const int j = remaining[index];
-      const int rj = row4col[j];
-      if (rj == -1) sink = j; else i = rj;
-      __syncthreads();  // all lanes have read remaining[]/row4col[] before the update
-      if (lane == 0) {
-        SC[j] = 1;
-        remaining[index] = remaining[num_remaining - 1];
-      }
-      --num_remaining;
-      __syncthreads();
-    }
-    if (fail) break;
-    // dual updates
-    for (int r = lane; r < n; r += 64) {
-      if (r == cur) u[r] += minVal;
-      else if (SR[r]) u[r] += minVal - spc[col4row[r]];
-    }
-    for (int c = lane; c < n; c += 64)
-      if (SC[c]) v[c] -= minVal - spc[c];
-    __syncthreads();
-    // augment along the path (serial, wave-uniform)
-    if (lane == 0) {
-      int j = sink;
-      for (;;) {
-        const int r = path[j];
-        row4col[j] = r;
-        const int t = col4row[r];
-        col4row[r] = j;
-        j = t;
-        if (r == cur) break;
-      }
-    }
-    __syncthreads();
   }
-  if (fail) {
-    if (lane == 0) status[g] = 1;
-    return;
-  }
-  // perm[col4row[i]] = i
-  for (int r = lane; r < n; r += 64) pg[col4row[r]] = r;
-  if (lane == 0) status[g] = 0;
+  if (lane == 0) status[g] = fail;
 }
 
 }  // namespace gvae
@@ -190,8 +241,7 @@ extern "C" int gvae_lsap(const float *d_X, int ldx, int64_t strideX, const int32
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && n_perm >= r_max, GVAE_EINVAL,
                "lsap: bad sizes (n_graphs=%d r_max=%d ldx=%d n_perm=%d)", n_graphs, r_max, ldx,
                n_perm);
-  const int np = (r_max + 1) & ~1;
-  const size_t lds = (size_t)np * (3 * 8 + 6 * 4) + (size_t)r_max * r_max * 4;
+  const size_t lds = (size_t)r_max * r_max * 4;
   GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
                "lsap: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", r_max, lds);
   if (n_graphs == 0) return GVAE_OK;
