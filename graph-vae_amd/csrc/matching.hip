@@ -180,18 +180,19 @@ __device__ __forceinline__ float group_max(float m, int lpr_log2) {
 }
 
 // The slab holds R*R rows (j,a) of RS floats = cols vectors of V floats (RS = R, or R rounded
-// up to a multiple of 4 with the row's last element repeated).  A row is shared by
-// lpr = 2^lpr_log2 adjacent lanes; lane lr of the group takes the vectors lr, lr + lpr, ...
-// (PASSES of them; indices past the row end are clamped to its last vector: a duplicate
-// cannot change a maximum).  RB rows per group are in flight at a time, so a lane has
-// RB*PASSES independent loads outstanding.  Xs holds X with the same row stride and the same
-// repeated padding.  T[row] receives max_b S[i,j,a,b]*X[j,b] for every row, j == i included.
+// up to a multiple of 4 with the row's last element repeated).  One call handles the rows
+// (j, a0 + al) for all j and al in [0, Aw): NR = R*Aw rows, numbered r' = j*Aw + al.  A row is
+// shared by lpr = 2^lpr_log2 adjacent lanes; lane lr of the group takes the vectors lr,
+// lr + lpr, ... (PASSES of them; indices past the row end are clamped to its last vector: a
+// duplicate cannot change a maximum).  RB rows per group are in flight at a time, so a lane
+// has RB*PASSES independent loads outstanding.  Xs holds X with the same row stride and the
+// same repeated padding.  T[r'] receives max_b S[i,j,a,b]*X[j,b] for every row, j == i included.
 template <int V, int PASSES, int RB>
-__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS,
-                                              int lpr_log2, const float *Xs, float *T) {
+__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS, int a0,
+                                              int Aw, int lpr_log2, const float *Xs, float *T) {
   using vec_t = typename VecT<V>::type;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int R2 = R * R;
+  const int NR = R * Aw;
   const int cols = RS / V;
   const int lpr = 1 << lpr_log2;
   const int lr = tid & (lpr - 1);
@@ -201,23 +202,36 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) coff[p] = min(lr + p * lpr, cols - 1) * V;
 
-  // (j*RS, a) of this group's current row, advanced incrementally (no division in the loop)
-  int a = row0 % R, jX = (row0 / R) * RS;
-  const int dj = rpp / R, da = rpp - dj * R, djX = dj * RS;
-  const int jX_last = (R - 1) * RS;
+  // this group's current row: al, its X row offset jX = j*RS and its slab offset
+  // so = (j*R + a0 + al)*RS, advanced incrementally (no division in the loop)
+  const int j0 = row0 / Aw;
+  int al = row0 - j0 * Aw, jX = j0 * RS, so = (j0 * R + a0 + al) * RS;
+  const int dj = rpp / Aw, da = rpp - dj * Aw;
+  const int djX = dj * RS, dso = (dj * R + da) * RS, wrap_so = (R - Aw) * RS;
 
-  for (int row = row0; row < R2; row += rpp * RB) {
+  for (int row = row0; row < NR; row += rpp * RB) {
     vec_t sv[RB][PASSES];
+    int jXs[RB];
+    const int so_first = so, jX_first = jX;   // the first row of a step is always valid
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int r = min(row + rb * rpp, R2 - 1);
-      const float *src = slab + (unsigned)(r * RS);
+      const bool ok = row + rb * rpp < NR;    // rows past the end re-read the step's first row
+      const float *src = slab + (unsigned)(ok ? so : so_first);
+      jXs[rb] = ok ? jX : jX_first;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) sv[rb][p] = stream_load<V>(src + coff[p]);
+      al += da;
+      jX += djX;
+      so += dso;
+      if (al >= Aw) {
+        al -= Aw;
+        jX += RS;
+        so += wrap_so;
+      }
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const float *xr = Xs + min(jX, jX_last);
+      const float *xr = Xs + jXs[rb];
       float m = -INFINITY;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
@@ -229,13 +243,7 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
       }
       m = group_max(m, lpr_log2);
       const int r_u = row + rb * rpp;
-      if (lr == 0 && r_u < R2) T[r_u] = m;
-      a += da;
-      jX += djX;
-      if (a >= R) {
-        a -= R;
-        jX += RS;
-      }
+      if (lr == 0 && r_u < NR) T[r_u] = m;
     }
   }
 }
@@ -244,13 +252,13 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
 #define GVAE_STREAM_DEPTH 4
 #endif
 #ifndef GVAE_STREAM_WAVES
-#define GVAE_STREAM_WAVES 8
+#define GVAE_STREAM_WAVES 7
 #endif
 // picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
 template <int V>
 __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R, int RS,
-                                                  const float *Xs, float *T) {
+                                                  int a0, int Aw, const float *Xs, float *T) {
   const int cols = RS / V;
   int lpr_log2 = 0;
   constexpr int kBase = V == 4 ? 3 : (V == 2 ? 4 : 5);
@@ -258,10 +266,10 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
   while ((cols + (1 << lpr_log2) - 1) >> lpr_log2 > 4) ++lpr_log2;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
   constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
-  if (passes == 1) mpm_iter_body<V, 1, D>(slab, R, RS, lpr_log2, Xs, T);
-  else if (passes == 2) mpm_iter_body<V, 2, D / 2>(slab, R, RS, lpr_log2, Xs, T);
-  else if (passes == 3) mpm_iter_body<V, 3, (D + 2) / 3>(slab, R, RS, lpr_log2, Xs, T);
-  else mpm_iter_body<V, 4, D / 4>(slab, R, RS, lpr_log2, Xs, T);
+  if (passes == 1) mpm_iter_body<V, 1, D>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
+  else if (passes == 2) mpm_iter_body<V, 2, D / 2>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
+  else if (passes == 3) mpm_iter_body<V, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
+  else mpm_iter_body<V, 4, D / 4>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
 }
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
@@ -303,9 +311,11 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 }
 
 // The whole MPM of a batch in ONE launch, driven by a work queue.
-//   * work item = (graph g, row i) of one iteration: stream the slab S[g][i,:,:,:] once and
-//     produce row i of Xnew[g];
-//   * the R producers of a graph hand their rows to whichever of them arrives last (per-graph
+//   * work item = (graph g, row i, column block q) of one iteration: stream the rows (j, a) of
+//     the slab S[g][i,:,:,:] for all j and the a of block q once and produce those columns of
+//     row i of Xnew[g].  A slab of up to 2 MiB is one block; larger slabs are cut into up to 8
+//     column blocks (mpm_col_block), so that one large graph can occupy the whole device;
+//   * the producers of a graph hand their pieces to whichever of them arrives last (per-graph
 //     arrival counter: rows stored write-through and drained before the producer's ticket,
 //     agent-scope acquire by the last arriver before it reads them).  That work-group
 //     normalises (nrm = ||Xnew||_2 in canonical order, X = Xnew / nrm) and, unless the graph
@@ -314,7 +324,7 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 //   * the queue is a ring of 8-byte {generation, item} granules with a head and a tail ticket
 //     counter.  A consumer draws a ticket and polls ITS OWN slot until the granule of its
 //     generation appears (or until no graph is left), then clears the slot.  At most
-//     sum_g R_g <= capacity items are ever undrawn (a graph's next items are pushed only after
+//     sum_g (items of g) <= capacity items are ever undrawn (a graph's next items are pushed only after
 //     all of its current ones were consumed), so when a producer reaches a slot the ticket one
 //     lap earlier has already been drawn; it only has to wait for that consumer's clear, which
 //     never depends on another work-group.  Every spin is bounded and reports through the
@@ -322,6 +332,17 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
 // everything else instead of costing one under-filled launch per iteration.
 #define MPM_NULL_ITEM 0xFFFFFFFFu
+// item word: graph (16 bits) | row i (8 bits) | column block q (4 bits)
+#define MPM_ITEM(g, i, q) (((unsigned)(g) << 12) | ((unsigned)(i) << 4) | (unsigned)(q))
+
+// width of a column block of an R-node graph (rows of RS floats): ceil(R / Q) with
+// Q = slab bytes / 2 MiB rounded up, at most 8; the graph then has ceil(R / width) blocks
+__host__ __device__ __forceinline__ int mpm_col_block(int R, int RS) {
+  const long long slab = 4LL * R * R * RS;
+  long long Q = (slab + (2LL << 20) - 1) >> 21;
+  Q = Q < 1 ? 1 : (Q > 8 ? 8 : Q);
+  return (R + (int)Q - 1) / (int)Q;
+}
 #define MPM_SPIN_LIMIT (1u << 21)
 
 struct MpmQueue {
@@ -401,10 +422,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
     ++ss_items;
 #endif
     if ((unsigned)item != MPM_NULL_ITEM) {
-      const int g = item / r_max, i = item - g * r_max;
+      const int g = item >> 12, i = (item >> 4) & 0xFF, q_blk = item & 0xF;
       const int R = Rarr[g];
       const int R2 = R * R;
       const int RS = s_row_stride(R, layout);
+      const int Aw_full = mpm_col_block(R, RS);
+      const int n_blk = (R + Aw_full - 1) / Aw_full;          // column blocks per row i
+      const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
       float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
       float *T = lds + R * RS;    // R*R
       float *nsrow = T + R2;      // R
@@ -415,19 +439,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         Xs[e] = Xg[(int64_t)r * ldx + min(c, R - 1)];
       }
       // S[i,i,a,a], the factor of X[i,a] in the update
-      for (int p = tid; p < R; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
+      for (int p = a0 + tid; p < a0 + Aw; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
       __syncthreads();
       SSTAMP(1);
-      if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, Xs, T);
-      else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, Xs, T);
-      else mpm_iter_dispatch<1>(slab, R, RS, Xs, T);
+      if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
+      else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
+      else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
       __syncthreads();
       SSTAMP(2);
       float *Xn = Xnew + g * strideXnew;
-      for (int p = tid; p < R; p += nt) {
+      for (int p = a0 + tid; p < a0 + Aw; p += nt) {
         // the row j == i does not take part in the sum: an exact +0 at its position
-        const float et =
-            column_sum([&](int jj) { return jj == i ? 0.0f : T[jj * R + p]; }, p, R);
+        const float et = column_sum(
+            [&](int jj) { return jj == i ? 0.0f : T[jj * Aw + (p - a0)]; }, p, R);
         // write-through store (no release fence needed for a write-through payload)
         __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsrow[p] + et, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -439,7 +463,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       if (tid == 0) {
         const int ticket =
             __hip_atomic_fetch_add(&q.arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == R - 1) ? 1 : 0;
+        const int last = (ticket == R * n_blk - 1) ? 1 : 0;
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_last = last;
       }
@@ -487,7 +511,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_store(&q.arrive[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
           if (cont)
-            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R * n_blk, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
           s_cont = cont;
         }
         // X, the iteration count and the reset counter are drained before anything is pushed
@@ -496,10 +521,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         SSTAMP(7);
         if (s_cont) {
           const unsigned base = (unsigned)s_base;
-          for (int p = tid; p < R; p += nt) {
+          for (int p = tid; p < R * n_blk; p += nt) {
             const unsigned t = base + (unsigned)p;
-            const unsigned long long gran =
-                ((unsigned long long)(t / q.cap + 1u) << 32) | (unsigned)(g * r_max + p);
+            const unsigned long long gran = ((unsigned long long)(t / q.cap + 1u) << 32) |
+                                            MPM_ITEM(g, p / n_blk, p % n_blk);
             unsigned long long *sl = &q.slots[t % q.cap];
             // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
             // undrawn), so its consumer is polling this slot and frees it promptly
@@ -530,20 +555,58 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
 #endif
 }
 
-// first generation of the ring: one slot per (graph, i < r_max); rows beyond R are null items
-__global__ void mpm_queue_init_kernel(MpmQueue q, const int32_t *__restrict__ Rarr, int n_graphs,
-                                      int r_max, int32_t *__restrict__ iters_done) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_graphs * r_max) return;
-  const int g = t / r_max, i = t - g * r_max;
-  const int R = Rarr[g];
-  q.slots[t] = (1ull << 32) | (i < R ? (unsigned)t : MPM_NULL_ITEM);
-  if (i == 0) {
+// first generation of the ring, compact: the items of graph g start at the sum of the item
+// counts of the graphs before it (one work-group: block scan over the graphs, then the fill).
+// The slots beyond the total stay empty (zeroed by the host) until the tail reaches them.
+__global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
+                                                              const int32_t *__restrict__ Rarr,
+                                                              int n_graphs, int layout,
+                                                              int32_t *__restrict__ iters_done) {
+  __shared__ int s_part[1024];
+  __shared__ int s_live[1024];
+  const int tid = threadIdx.x;
+  const int per = (n_graphs + 1023) / 1024;
+  const int g_lo = min(tid * per, n_graphs), g_hi = min(g_lo + per, n_graphs);
+  auto items_of = [&](int g, int &n_blk) {
+    const int R = Rarr[g];
+    if (R <= 0) { n_blk = 0; return 0; }
+    const int Aw = mpm_col_block(R, s_row_stride(R, layout));
+    n_blk = (R + Aw - 1) / Aw;
+    return R * n_blk;
+  };
+  int mine = 0, live = 0;
+  for (int g = g_lo; g < g_hi; ++g) {
+    int nb;
+    const int n = items_of(g, nb);
+    mine += n;
+    live += n > 0;
     q.arrive[g] = 0;
     iters_done[g] = 0;
-    if (R > 0) atomicAdd(Q_REMAIN(q), 1);
   }
-  if (t == 0) *Q_TAIL(q) = n_graphs * r_max;
+  s_part[tid] = mine;
+  s_live[tid] = live;
+  __syncthreads();
+  // inclusive scan (Hillis-Steele over 1024 entries)
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? s_part[tid - off] : 0;
+    const int l = tid >= off ? s_live[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    s_live[tid] += l;
+    __syncthreads();
+  }
+  int pos = s_part[tid] - mine;
+  for (int g = g_lo; g < g_hi; ++g) {
+    int nb;
+    const int n = items_of(g, nb);
+    for (int k = 0; k < n; ++k)
+      q.slots[pos + k] = (1ull << 32) | MPM_ITEM(g, k / nb, k % nb);
+    pos += n;
+  }
+  if (tid == 1023) {
+    *Q_TAIL(q) = s_part[1023];
+    *Q_REMAIN(q) = s_live[1023];
+  }
 }
 
 
@@ -878,9 +941,16 @@ int gvae_edge_sim(const float *d_A, const float *d_P, const float *d_NS, const i
 
 static inline int64_t pad256(int64_t b) { return (b + 255) & ~255LL; }
 
+// ring capacity: an upper bound of the items a batch can have outstanding
+static inline int64_t mpm_queue_cap(int n_graphs, int r_max) {
+  const int RS = (r_max + 3) & ~3;
+  const int Aw = mpm_col_block(r_max, RS);
+  return (int64_t)n_graphs * r_max * ((r_max + Aw - 1) / Aw);
+}
+
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
-  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (n_graphs*ldx granules) | arrive
-  return pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 + pad256(8LL * n_graphs * ldx) +
+  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (granules) | arrive
+  return pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 + pad256(8 * mpm_queue_cap(n_graphs, ldx)) +
          pad256(4LL * n_graphs);
 }
 
@@ -892,7 +962,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "mpm_stream: bad sizes (n_graphs=%d r_max=%d ldx=%d iters=%d)", n_graphs, r_max, ldx,
                iters);
-  GVAE_REQUIRE((int64_t)n_graphs * r_max < (1LL << 30), GVAE_ELIMIT, "mpm_stream: too many graphs");
+  GVAE_REQUIRE(n_graphs <= 65535 && r_max <= 255 && mpm_queue_cap(n_graphs, r_max) < (1LL << 30),
+               GVAE_ELIMIT, "mpm_stream: too many graphs (n_graphs=%d, r_max=%d)", n_graphs, r_max);
   GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
                "mpm_stream: unknown S layout %d", s_layout);
   const size_t lds =
@@ -913,15 +984,16 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   q.words = (int32_t *)w;
   w += 512;
   q.slots = (unsigned long long *)w;
-  w += pad256(8LL * n_graphs * ldx);
+  w += pad256(8 * mpm_queue_cap(n_graphs, ldx));
   q.arrive = (int32_t *)w;
-  const int n_items = n_graphs * r_max;
+  const int64_t n_items = mpm_queue_cap(n_graphs, r_max);
   q.cap = (unsigned)n_items;
   const int64_t strideXnew = (int64_t)ldx * ldx;
-  GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess, GVAE_ELAUNCH,
-               "mpm_stream: memset failed");
-  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(ceil_div(n_items, 256)), dim3(256), 0, s, q, d_R,
-                     n_graphs, r_max, d_iters_done);
+  GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess &&
+                   hipMemsetAsync(q.slots, 0, 8 * (size_t)n_items, s) == hipSuccess,
+               GVAE_ELAUNCH, "mpm_stream: memset failed");
+  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, s_layout,
+                     d_iters_done);
   // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
   // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
   const int nt = r_max >= 48 ? 1024 : 256;
@@ -934,7 +1006,7 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
   // others leave, which only happens once every graph is finished, and then leave at once
   const int max_blocks = 2048 * 256 / nt;
-  const int blocks = n_items < max_blocks ? n_items : max_blocks;
+  const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   {
     ProfileScope ps(F_MPM_ITER, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
