@@ -4,6 +4,6 @@
 for lib in tmp_ab/*.so; do
   for args in "$@"; do
     echo "== $lib :: $args"
-    GVAE_HIP_LIB=$PWD/$lib timeout -k 10 120 python3 benchmarks/matching_bench.py $args | grep -E "mpm_stream N|mpm_fused|lsap" || exit 1
+    GVAE_HIP_LIB=$PWD/$lib timeout -k 10 120 python3 benchmarks/matching_bench.py $args | grep -E "mpm_stream wall" || exit 1
   done
 done

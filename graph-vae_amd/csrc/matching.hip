@@ -313,8 +313,9 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // The whole MPM of a batch in ONE launch, driven by a work queue.
 //   * work item = (graph g, row i, column block q) of one iteration: stream the rows (j, a) of
 //     the slab S[g][i,:,:,:] for all j and the a of block q once and produce those columns of
-//     row i of Xnew[g].  A slab of up to 2 MiB is one block; larger slabs are cut into up to 8
-//     column blocks (mpm_col_block), so that one large graph can occupy the whole device;
+//     row i of Xnew[g].  A slab of up to 2 MiB is one block; larger slabs, and the slabs of
+//     the last few unconverged graphs of a batch, are cut into up to 8 column blocks
+//     (mpm_col_blocks), chosen anew at every iteration of a graph;
 //   * the producers of a graph hand their pieces to whichever of them arrives last (per-graph
 //     arrival counter: rows stored write-through and drained before the producer's ticket,
 //     agent-scope acquire by the last arriver before it reads them).  That work-group
@@ -332,24 +333,41 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
 // everything else instead of costing one under-filled launch per iteration.
 #define MPM_NULL_ITEM 0xFFFFFFFFu
-// item word: graph (16 bits) | row i (8 bits) | column block q (4 bits)
-#define MPM_ITEM(g, i, q) (((unsigned)(g) << 12) | ((unsigned)(i) << 4) | (unsigned)(q))
-
-// width of a column block of an R-node graph (rows of RS floats): ceil(R / Q) with
-// Q = slab bytes / 2 MiB rounded up, at most 8; the graph then has ceil(R / width) blocks
-__host__ __device__ __forceinline__ int mpm_col_block(int R, int RS) {
-  const long long slab = 4LL * R * R * RS;
-  long long Q = (slab + (2LL << 20) - 1) >> 21;
-  Q = Q < 1 ? 1 : (Q > 8 ? 8 : Q);
-  return (R + (int)Q - 1) / (int)Q;
-}
+// item word: graph (16 bits) | row i (8 bits) | column block q (4 bits) | blocks per row (4 bits)
+#define MPM_ITEM(g, i, q, nb) \
+  (((unsigned)(g) << 16) | ((unsigned)(i) << 8) | ((unsigned)(q) << 4) | (unsigned)(nb))
+#define MPM_MAX_COL_BLOCKS 8
 #define MPM_SPIN_LIMIT (1u << 21)
+
+// Column blocks per row of an R-node graph.  Base rule: slab bytes / 2 MiB rounded up, so that
+// one large graph can occupy the whole device.  When the items in flight (graphs still
+// iterating x R x blocks) are fewer than `low`, the rows are cut finer: a nearly empty device
+// is bound by the latency of a graph's chain of iterations, and smaller pieces shorten the
+// streaming phase of each link (measured: worth it only below a few hundred items; every item
+// also costs about 12 ns of serialised queue traffic).  The result nb satisfies
+// nb == ceil(R / ceil(R / nb)), so a consumer recovers the block width from nb alone.
+__host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low) {
+  const long long slab = 4LL * R * R * RS;
+  long long t = (slab + (2LL << 20) - 1) >> 21;
+  t = t < 1 ? 1 : t;
+  const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R * t;
+  if (in_flight < low) t *= low / in_flight;
+  int nb = t > MPM_MAX_COL_BLOCKS ? MPM_MAX_COL_BLOCKS : (int)t;
+  nb = nb > R ? R : nb;
+  for (;;) {
+    const int Aw = (R + nb - 1) / nb;
+    const int nb2 = (R + Aw - 1) / Aw;
+    if (nb2 == nb) return nb;
+    nb = nb2;
+  }
+}
 
 struct MpmQueue {
   unsigned long long *slots;  // [cap]
   int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [96] error
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
+  int low;                    // items in flight below which rows are cut into more column blocks
 };
 #define Q_HEAD(q) ((q).words + 0)
 #define Q_TAIL(q) ((q).words + 32)
@@ -374,7 +392,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
   extern __shared__ float lds[];
   __shared__ float red[16];
   __shared__ float s_nrm;
-  __shared__ int s_item, s_last, s_cont, s_base;
+  __shared__ int s_item, s_last, s_cont, s_base, s_nb;
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef GVAE_STREAM_STAMPS
   long long ss_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -422,12 +440,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
     ++ss_items;
 #endif
     if ((unsigned)item != MPM_NULL_ITEM) {
-      const int g = item >> 12, i = (item >> 4) & 0xFF, q_blk = item & 0xF;
+      const int g = (unsigned)item >> 16, i = (item >> 8) & 0xFF, q_blk = (item >> 4) & 0xF;
+      const int n_blk = item & 0xF;                           // column blocks per row i
       const int R = Rarr[g];
       const int R2 = R * R;
       const int RS = s_row_stride(R, layout);
-      const int Aw_full = mpm_col_block(R, RS);
-      const int n_blk = (R + Aw_full - 1) / Aw_full;          // column blocks per row i
+      const int Aw_full = (R + n_blk - 1) / n_blk;
       const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
       float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
       float *T = lds + R * RS;    // R*R
@@ -510,9 +528,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_store(&iters_done[g], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&q.arrive[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
-          if (cont)
-            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R * n_blk, __ATOMIC_RELAXED,
+          if (cont) {
+            const int alive =
+                __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nb = mpm_col_blocks(R, RS, alive, q.low);
+            s_nb = nb;
+            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R * nb, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
+          }
           s_cont = cont;
         }
         // X, the iteration count and the reset counter are drained before anything is pushed
@@ -521,10 +544,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         SSTAMP(7);
         if (s_cont) {
           const unsigned base = (unsigned)s_base;
-          for (int p = tid; p < R * n_blk; p += nt) {
+          const int nb = s_nb;
+          for (int p = tid; p < R * nb; p += nt) {
             const unsigned t = base + (unsigned)p;
             const unsigned long long gran = ((unsigned long long)(t / q.cap + 1u) << 32) |
-                                            MPM_ITEM(g, p / n_blk, p % n_blk);
+                                            MPM_ITEM(g, p / nb, p % nb, nb);
             unsigned long long *sl = &q.slots[t % q.cap];
             // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
             // undrawn), so its consumer is polling this slot and frees it promptly
@@ -570,8 +594,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
   auto items_of = [&](int g, int &n_blk) {
     const int R = Rarr[g];
     if (R <= 0) { n_blk = 0; return 0; }
-    const int Aw = mpm_col_block(R, s_row_stride(R, layout));
-    n_blk = (R + Aw - 1) / Aw;
+    n_blk = mpm_col_blocks(R, s_row_stride(R, layout), n_graphs, q.low);
     return R * n_blk;
   };
   int mine = 0, live = 0;
@@ -600,7 +623,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     int nb;
     const int n = items_of(g, nb);
     for (int k = 0; k < n; ++k)
-      q.slots[pos + k] = (1ull << 32) | MPM_ITEM(g, k / nb, k % nb);
+      q.slots[pos + k] = (1ull << 32) | MPM_ITEM(g, k / nb, k % nb, nb);
     pos += n;
   }
   if (tid == 1023) {
@@ -943,9 +966,7 @@ static inline int64_t pad256(int64_t b) { return (b + 255) & ~255LL; }
 
 // ring capacity: an upper bound of the items a batch can have outstanding
 static inline int64_t mpm_queue_cap(int n_graphs, int r_max) {
-  const int RS = (r_max + 3) & ~3;
-  const int Aw = mpm_col_block(r_max, RS);
-  return (int64_t)n_graphs * r_max * ((r_max + Aw - 1) / Aw);
+  return (int64_t)n_graphs * r_max * MPM_MAX_COL_BLOCKS;
 }
 
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
@@ -992,8 +1013,6 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess &&
                    hipMemsetAsync(q.slots, 0, 8 * (size_t)n_items, s) == hipSuccess,
                GVAE_ELAUNCH, "mpm_stream: memset failed");
-  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, s_layout,
-                     d_iters_done);
   // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
   // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
   const int nt = r_max >= 48 ? 1024 : 256;
@@ -1007,6 +1026,9 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   // others leave, which only happens once every graph is finished, and then leave at once
   const int max_blocks = 2048 * 256 / nt;
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
+  q.low = 256;
+  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, s_layout,
+                     d_iters_done);
   {
     ProfileScope ps(F_MPM_ITER, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
