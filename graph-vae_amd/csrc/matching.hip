@@ -333,7 +333,7 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // Graphs advance independently: a slow-converging graph's chain of iterations overlaps with
 // everything else instead of costing one under-filled launch per iteration.
 #define MPM_NULL_ITEM 0xFFFFFFFFu
-// item word: graph (16 bits) | row i (8 bits) | column block q (4 bits) | blocks per row (4 bits)
+// item word: graph (16 bits) | first row i (8 bits) | column block q (4 bits) | shape code (4 bits)
 #define MPM_ITEM(g, i, q, nb) \
   (((unsigned)(g) << 16) | ((unsigned)(i) << 8) | ((unsigned)(q) << 4) | (unsigned)(nb))
 #define MPM_MAX_COL_BLOCKS 8
@@ -362,12 +362,40 @@ __host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive,
   }
 }
 
+// Shape of a graph's work items for one iteration, as a 4-bit code:
+//   1..8   one row i per item, cut into that many column blocks (mpm_col_blocks);
+//   9..11  2, 4 or 8 consecutive rows i per item (whole rows): with many small slabs in flight
+//          the per-item costs (ticket, X reload, hand-off: about 12 ns of them serialised over
+//          the whole device) weigh more than the loss of parallelism, so items are made
+//          larger, up to about 512 KiB, as long as `high` items stay in flight.
+__host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive, int low, int high) {
+  const long long slab = 4LL * R * R * RS;
+  const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R;
+  int code = 0;
+  for (int rpi = 8, c = 11; rpi >= 2; rpi >>= 1, --c)
+    if (!code && slab * rpi <= (512LL << 10) && in_flight / rpi >= high && rpi <= R) code = c;
+  return code ? code : mpm_col_blocks(R, RS, alive, low);
+}
+__host__ __device__ __forceinline__ int mpm_shape_blocks(int code) { return code <= 8 ? code : 1; }
+__host__ __device__ __forceinline__ int mpm_shape_rows(int code) { return code <= 8 ? 1 : 2 << (code - 9); }
+// items of one iteration of an R-node graph in that shape
+__host__ __device__ __forceinline__ int mpm_shape_items(int R, int code) {
+  const int rpi = mpm_shape_rows(code);
+  return rpi > 1 ? (R + rpi - 1) / rpi : R * code;
+}
+// item number p of the iteration -> item word
+__host__ __device__ __forceinline__ unsigned mpm_shape_item(int g, int p, int code) {
+  const int rpi = mpm_shape_rows(code);
+  return rpi > 1 ? MPM_ITEM(g, p * rpi, 0, code) : MPM_ITEM(g, p / code, p % code, code);
+}
+
 struct MpmQueue {
   unsigned long long *slots;  // [cap]
   int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [96] error
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
   int low;                    // items in flight below which rows are cut into more column blocks
+  int high;                   // items in flight that must remain when rows are grouped
 };
 #define Q_HEAD(q) ((q).words + 0)
 #define Q_TAIL(q) ((q).words + 32)
@@ -440,48 +468,54 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
     ++ss_items;
 #endif
     if ((unsigned)item != MPM_NULL_ITEM) {
-      const int g = (unsigned)item >> 16, i = (item >> 8) & 0xFF, q_blk = (item >> 4) & 0xF;
-      const int n_blk = item & 0xF;                           // column blocks per row i
+      const int g = (unsigned)item >> 16, i0 = (item >> 8) & 0xFF, q_blk = (item >> 4) & 0xF;
+      const int shape = item & 0xF;
+      const int n_blk = mpm_shape_blocks(shape);              // column blocks per row i
       const int R = Rarr[g];
       const int R2 = R * R;
       const int RS = s_row_stride(R, layout);
+      const int rows_here = min(mpm_shape_rows(shape), R - i0);
       const int Aw_full = (R + n_blk - 1) / n_blk;
       const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
       float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
       float *T = lds + R * RS;    // R*R
       float *nsrow = T + R2;      // R
       float *Xg = X + g * strideX;
-      const float *slab = S + S_off[g] + (int64_t)i * R2 * RS;
+      float *Xn = Xnew + g * strideXnew;
       for (int e = tid; e < R * RS; e += nt) {
         const int r = e / RS, c = e - r * RS;
         Xs[e] = Xg[(int64_t)r * ldx + min(c, R - 1)];
       }
-      // S[i,i,a,a], the factor of X[i,a] in the update
-      for (int p = a0 + tid; p < a0 + Aw; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
-      __syncthreads();
-      SSTAMP(1);
-      if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
-      else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
-      else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
-      __syncthreads();
-      SSTAMP(2);
-      float *Xn = Xnew + g * strideXnew;
-      for (int p = a0 + tid; p < a0 + Aw; p += nt) {
-        // the row j == i does not take part in the sum: an exact +0 at its position
-        const float et = column_sum(
-            [&](int jj) { return jj == i ? 0.0f : T[jj * Aw + (p - a0)]; }, p, R);
-        // write-through store (no release fence needed for a write-through payload)
-        __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsrow[p] + et, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int ri = 0; ri < rows_here; ++ri) {
+        const int i = i0 + ri;
+        const float *slab = S + S_off[g] + (int64_t)i * R2 * RS;
+        // S[i,i,a,a], the factor of X[i,a] in the update
+        for (int p = a0 + tid; p < a0 + Aw; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
+        __syncthreads();
+        SSTAMP(1);
+        if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
+        else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
+        else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
+        __syncthreads();
+        SSTAMP(2);
+        for (int p = a0 + tid; p < a0 + Aw; p += nt) {
+          // the row j == i does not take part in the sum: an exact +0 at its position
+          const float et = column_sum(
+              [&](int jj) { return jj == i ? 0.0f : T[jj * Aw + (p - a0)]; }, p, R);
+          // write-through store (no release fence needed for a write-through payload)
+          __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsrow[p] + et, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ri + 1 < rows_here) __syncthreads();   // T and nsrow are rewritten for the next row
       }
       // publish this row: every storing wave drains its stores, then one lane takes a ticket
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       SSTAMP(3);
       if (tid == 0) {
-        const int ticket =
-            __hip_atomic_fetch_add(&q.arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == R * n_blk - 1) ? 1 : 0;
+        const int before = __hip_atomic_fetch_add(&q.arrive[g], rows_here, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (before + rows_here == R * n_blk) ? 1 : 0;
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_last = last;
       }
@@ -531,10 +565,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           if (cont) {
             const int alive =
                 __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int nb = mpm_col_blocks(R, RS, alive, q.low);
-            s_nb = nb;
-            s_base = __hip_atomic_fetch_add(Q_TAIL(q), R * nb, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
+            const int shape_next = mpm_item_shape(R, RS, alive, q.low, q.high);
+            s_nb = shape_next;
+            s_base = __hip_atomic_fetch_add(Q_TAIL(q), mpm_shape_items(R, shape_next),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           s_cont = cont;
         }
@@ -544,11 +578,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         SSTAMP(7);
         if (s_cont) {
           const unsigned base = (unsigned)s_base;
-          const int nb = s_nb;
-          for (int p = tid; p < R * nb; p += nt) {
+          const int shape_next = s_nb, n_next = mpm_shape_items(R, shape_next);
+          for (int p = tid; p < n_next; p += nt) {
             const unsigned t = base + (unsigned)p;
             const unsigned long long gran = ((unsigned long long)(t / q.cap + 1u) << 32) |
-                                            MPM_ITEM(g, p / nb, p % nb, nb);
+                                            mpm_shape_item(g, p, shape_next);
             unsigned long long *sl = &q.slots[t % q.cap];
             // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
             // undrawn), so its consumer is polling this slot and frees it promptly
@@ -591,11 +625,11 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
   const int tid = threadIdx.x;
   const int per = (n_graphs + 1023) / 1024;
   const int g_lo = min(tid * per, n_graphs), g_hi = min(g_lo + per, n_graphs);
-  auto items_of = [&](int g, int &n_blk) {
+  auto items_of = [&](int g, int &shape) {
     const int R = Rarr[g];
-    if (R <= 0) { n_blk = 0; return 0; }
-    n_blk = mpm_col_blocks(R, s_row_stride(R, layout), n_graphs, q.low);
-    return R * n_blk;
+    if (R <= 0) { shape = 0; return 0; }
+    shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high);
+    return mpm_shape_items(R, shape);
   };
   int mine = 0, live = 0;
   for (int g = g_lo; g < g_hi; ++g) {
@@ -623,7 +657,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     int nb;
     const int n = items_of(g, nb);
     for (int k = 0; k < n; ++k)
-      q.slots[pos + k] = (1ull << 32) | MPM_ITEM(g, k / nb, k % nb, nb);
+      q.slots[pos + k] = (1ull << 32) | mpm_shape_item(g, k, nb);
     pos += n;
   }
   if (tid == 1023) {
@@ -1027,6 +1061,7 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   const int max_blocks = 2048 * 256 / nt;
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   q.low = 256;
+  q.high = 2048;   // measured: 16-node graphs 3.0 -> 1.65 ms per 1024, 24-node 3.08 -> 2.67 ms per 512
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, s_layout,
                      d_iters_done);
   {
