@@ -79,7 +79,7 @@ def make_model_and_batches(args, rank, world, device, matching, n_batches=2):
 def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, engine=None):
     for s in range(warmup):
         step_fn(batches[s % len(batches)], 0.25, 1.0)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -88,11 +88,11 @@ def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, 
         if iters_acc is not None:
             iters_acc += engine.iters_done.sum()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -149,14 +149,33 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP step has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
+    # one GPU per rank; GVAE_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 code path
+    # on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+    backend = os.environ.get("GVAE_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    # stdout carries the JSON line and nothing else: until it is printed, file descriptor 1
+    # points at stderr, which also catches what native libraries write (RCCL's version banner)
+    sys.stdout.flush()
+    real_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+    # GVAE_BENCH_FORCE_DIST=1: a process group and the step's collectives even with one rank
+    force_dist = world == 1 and os.environ.get("GVAE_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29541")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if backend == "nccl":                              # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from graphvae import _hip
     from graphvae.train.train_ddp import TrainStep
+
+    def note(msg):
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     results = {}
     roof = None
@@ -166,14 +185,18 @@ def main():
         if leg == "fused" and not _hip.mpm_fused_supported(max(max(b.r_host) for b in batches)):
             continue
         host_batches = host_batches or host
-        if world > 1:
+        note(f"{leg}: model and batches ready")
+        if dist.is_initialized():
             dist.broadcast(model.flat_parameters(), src=0)
-        step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world)
+            note("parameters broadcast")
+        step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world, force_collectives=force_dist)
         eng = model._engine_for(batches[0])
         iters_acc = torch.zeros((), dtype=torch.int64, device=device)
         # W warm-up steps, then EXACTLY K timed steps (no instrumentation) -> `value`
         timed_steps(step_fn, batches, 0, args.warmup, world, device)
+        note("warm-up done")
         dt = timed_steps(step_fn, batches, args.steps, 0, world, device)
+        note(f"{args.steps} timed steps: {1e3 * dt / max(1, args.steps):.3f} ms per step")
         if leg == "stream":
             # roofline pass: the same K steps again with HIP events recorded around every
             # launch of the streaming MPM kernel (on the stream it is launched on)
@@ -241,10 +264,13 @@ def main():
                          "note": "same step with the S-free LDS-resident MPM (bit-identical results)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, host_batches, early_stop)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout_fd, 1)
+    os.close(real_stdout_fd)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -183,13 +183,14 @@ __device__ __forceinline__ float group_max(float m, int lpr_log2) {
 // up to a multiple of 4 with the row's last element repeated).  One call handles the rows
 // (j, a0 + al) for all j and al in [0, Aw): NR = R*Aw rows, numbered r' = j*Aw + al.  A row is
 // shared by lpr = 2^lpr_log2 adjacent lanes; lane lr of the group takes the vectors lr,
-// lr + lpr, ... (PASSES of them; indices past the row end are clamped to its last vector: a
-// duplicate cannot change a maximum).  RB rows per group are in flight at a time, so a lane
-// has RB*PASSES independent loads outstanding.  Xs holds X with the same row stride and the
-// same repeated padding.  T[r'] receives max_b S[i,j,a,b]*X[j,b] for every row, j == i included.
-template <int V, int PASSES, int RB>
-__device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS, int a0,
-                                              int Aw, int lpr_log2, const float *Xs, float *T) {
+// lr + lpr, ...  Xs holds X with the same row stride and the same repeated padding.
+// T[r'] receives max_b S[i,j,a,b]*X[j,b] for every row, j == i included.
+// This is the compact form for rows of 4- and 8-byte vectors (the dense layout with a node
+// count that is not a multiple of 4, which only the public matching entry points produce):
+// one row per group at a time, shape parameters at run time.
+template <int V>
+__device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS, int a0,
+                                           int Aw, int lpr_log2, const float *Xs, float *T) {
   using vec_t = typename VecT<V>::type;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int NR = R * Aw;
@@ -197,54 +198,30 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
   const int lpr = 1 << lpr_log2;
   const int lr = tid & (lpr - 1);
   const int rpp = nt >> lpr_log2;       // rows per step of the whole work-group
-  const int row0 = tid >> lpr_log2;
-  int coff[PASSES];
+  for (int row = tid >> lpr_log2; row < NR; row += rpp) {
+    const int j = row / Aw, al = row - j * Aw;
+    const float *src = slab + (unsigned)((j * R + a0 + al) * RS);
+    const float *xr = Xs + j * RS;
+    float m = -INFINITY;
+    for (int c = lr; c < cols; c += 4 * lpr) {
+      vec_t sv[4];
+      int cc[4];
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) coff[p] = min(lr + p * lpr, cols - 1) * V;
-
-  // this group's current row: al, its X row offset jX = j*RS and its slab offset
-  // so = (j*R + a0 + al)*RS, advanced incrementally (no division in the loop)
-  const int j0 = row0 / Aw;
-  int al = row0 - j0 * Aw, jX = j0 * RS, so = (j0 * R + a0 + al) * RS;
-  const int dj = rpp / Aw, da = rpp - dj * Aw;
-  const int djX = dj * RS, dso = (dj * R + da) * RS, wrap_so = (R - Aw) * RS;
-
-  for (int row = row0; row < NR; row += rpp * RB) {
-    vec_t sv[RB][PASSES];
-    int jXs[RB];
-    const int so_first = so, jX_first = jX;   // the first row of a step is always valid
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const bool ok = row + rb * rpp < NR;    // rows past the end re-read the step's first row
-      const float *src = slab + (unsigned)(ok ? so : so_first);
-      jXs[rb] = ok ? jX : jX_first;
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) sv[rb][p] = stream_load<V>(src + coff[p]);
-      al += da;
-      jX += djX;
-      so += dso;
-      if (al >= Aw) {
-        al -= Aw;
-        jX += RS;
-        so += wrap_so;
+      for (int u = 0; u < 4; ++u) {
+        cc[u] = min(c + u * lpr, cols - 1) * V;   // past the row end: its last vector again
+        sv[u] = stream_load<V>(src + cc[u]);
       }
-    }
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const float *xr = Xs + jXs[rb];
-      float m = -INFINITY;
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
+      for (int u = 0; u < 4; ++u) {
         float sx[V], x[V];
-        vec_to_arr<V>(sv[rb][p], sx);
-        vec_to_arr<V>(*reinterpret_cast<const vec_t *>(xr + coff[p]), x);
+        vec_to_arr<V>(sv[u], sx);
+        vec_to_arr<V>(*reinterpret_cast<const vec_t *>(xr + cc[u]), x);
 #pragma unroll
         for (int v = 0; v < V; ++v) m = fmaxf(m, sx[v] * x[v]);
       }
-      m = group_max(m, lpr_log2);
-      const int r_u = row + rb * rpp;
-      if (lr == 0 && r_u < NR) T[r_u] = m;
     }
+    m = group_max(m, lpr_log2);
+    if (lr == 0) T[row] = m;
   }
 }
 
@@ -252,8 +229,109 @@ __device__ __forceinline__ void mpm_iter_body(const float *__restrict__ slab, in
 #define GVAE_STREAM_DEPTH 4
 #endif
 #ifndef GVAE_STREAM_WAVES
-#define GVAE_STREAM_WAVES 7
+#define GVAE_STREAM_WAVES 5
 #endif
+
+// max with the lane a DPP pattern names, as ONE instruction (the compiler's own sequence for
+// fmaxf around a DPP move is four: it re-canonicalises both operands).  s_nop 1: a DPP read of
+// a register needs two wait states after the vector instruction that wrote it.
+#define GVAE_DPP_MAX(NAME, PATTERN)                                                      \
+  __device__ __forceinline__ float NAME(float m) {                                       \
+    float r;                                                                             \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " PATTERN " row_mask:0xf bank_mask:0xf"     \
+        : "=v"(r)                                                                        \
+        : "v"(m));                                                                       \
+    return r;                                                                            \
+  }
+GVAE_DPP_MAX(dpp_max_xor1, "quad_perm:[1,0,3,2]")
+GVAE_DPP_MAX(dpp_max_xor2, "quad_perm:[2,3,0,1]")
+GVAE_DPP_MAX(dpp_max_half_mirror, "row_half_mirror")
+GVAE_DPP_MAX(dpp_max_mirror, "row_mirror")
+template <int LPR_LOG2>
+__device__ __forceinline__ float group_max_ct(float m) {
+  if constexpr (LPR_LOG2 >= 1) m = dpp_max_xor1(m);
+  if constexpr (LPR_LOG2 >= 2) m = dpp_max_xor2(m);
+  if constexpr (LPR_LOG2 >= 3) m = dpp_max_half_mirror(m);
+  if constexpr (LPR_LOG2 >= 4) m = dpp_max_mirror(m);
+  return m;
+}
+
+// The same rows as mpm_iter_body for 16-byte vectors, with the lanes per row and the passes
+// fixed at compile time and no per-row control flow.  Every group runs the same number of
+// steps: rows past the end repeat the last row, which rewrites T[NR-1] with the same value.
+// The row -> (j, a) split is a multiplication by 1/Aw in fp32 (exact here: the quotient is
+// below 256 and (r + 0.5)/Aw stays 0.5/Aw away from an integer), 24-bit multiplies elsewhere.
+template <int LPR_LOG2, int PASSES, int RB>
+struct RowStep {
+  f32x4_t sv[RB][PASSES];
+  int jX[RB], rw[RB];
+};
+
+template <int LPR_LOG2, int PASSES, int RB>
+__device__ __forceinline__ void row_step_issue(RowStep<LPR_LOG2, PASSES, RB> &st,
+                                               const float *__restrict__ slab, int R, int RS, int a0,
+                                               int Aw, float inv_aw, int NR, int first_row, int rpp,
+                                               const int (&coff)[PASSES]) {
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int r = min(first_row + rb * rpp, NR - 1);
+    const int j = (int)(((float)r + 0.5f) * inv_aw);
+    const int al = r - __mul24(j, Aw);
+    const float *src = slab + (unsigned)__mul24(__mul24(j, R) + a0 + al, RS);
+    st.jX[rb] = __mul24(j, RS);
+    st.rw[rb] = r;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) st.sv[rb][p] = stream_load<4>(src + coff[p]);
+  }
+}
+
+template <int LPR_LOG2, int PASSES, int RB>
+__device__ __forceinline__ void row_step_reduce(const RowStep<LPR_LOG2, PASSES, RB> &st,
+                                                const float *Xs, float *T,
+                                                const int (&coff)[PASSES]) {
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float *xr = Xs + st.jX[rb];
+    float m = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const f32x4_t x = *reinterpret_cast<const f32x4_t *>(xr + coff[p]);
+      const f32x4_t sx = st.sv[rb][p];
+      m = fmaxf(m, sx.x * x.x);
+      m = fmaxf(m, sx.y * x.y);
+      m = fmaxf(m, sx.z * x.z);
+      m = fmaxf(m, sx.w * x.w);
+    }
+    T[st.rw[rb]] = group_max_ct<LPR_LOG2>(m);
+  }
+}
+
+template <int LPR_LOG2, int PASSES, int RB>
+__device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab, int R, int RS,
+                                                 int a0, int Aw, const float *Xs, float *T) {
+  constexpr int LPR = 1 << LPR_LOG2;
+  int tid = threadIdx.x;
+  // opaque to the optimiser: what derives from the lane number is computed here, per call,
+  // instead of once per shape at kernel entry (where it would stay live across every item)
+  asm volatile("" : "+v"(tid));
+  const int nt = blockDim.x;
+  const int NR = R * Aw, cols = RS >> 2;
+  const int lr = tid & (LPR - 1), grp = tid >> LPR_LOG2;
+  const int rpp = nt >> LPR_LOG2, step = rpp * RB;
+  const float inv_aw = 1.0f / (float)Aw;
+  int coff[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) coff[p] = min(lr + p * LPR, cols - 1) * 4;
+  // One buffer of RB*PASSES loads per lane.  Measured against a second buffer with the next
+  // step's loads in flight during the reduction: no gain at 32 nodes, 10 % slower at 64 (HBM
+  // does not reward more than about 64 KiB outstanding per compute unit).
+  RowStep<LPR_LOG2, PASSES, RB> A;
+  for (int base = 0; base < NR; base += step) {
+    row_step_issue(A, slab, R, RS, a0, Aw, inv_aw, NR, base + grp, rpp, coff);
+    row_step_reduce(A, Xs, T, coff);
+  }
+}
+
 // picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
 template <int V>
@@ -266,10 +344,22 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
   while ((cols + (1 << lpr_log2) - 1) >> lpr_log2 > 4) ++lpr_log2;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
   constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
-  if (passes == 1) mpm_iter_body<V, 1, D>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
-  else if (passes == 2) mpm_iter_body<V, 2, D / 2>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
-  else if (passes == 3) mpm_iter_body<V, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
-  else mpm_iter_body<V, 4, D / 4>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
+  if constexpr (V == 4) {
+    // every shape up to 35 vectors per row (R <= 140, the LDS limit of the kernel)
+    const int key = lpr_log2 * 8 + passes;
+    switch (key) {
+      case 0 * 8 + 1: return mpm_iter_body_v4<0, 1, D>(slab, R, RS, a0, Aw, Xs, T);
+      case 1 * 8 + 1: return mpm_iter_body_v4<1, 1, D>(slab, R, RS, a0, Aw, Xs, T);
+      case 2 * 8 + 1: return mpm_iter_body_v4<2, 1, D>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 1: return mpm_iter_body_v4<3, 1, D>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, D / 2>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, D / 4>(slab, R, RS, a0, Aw, Xs, T);
+      case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
+      default: break;
+    }
+  }
+  mpm_iter_body<V>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
 }
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
@@ -317,12 +407,12 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 //     the last few unconverged graphs of a batch, are cut into up to 8 column blocks
 //     (mpm_col_blocks), chosen anew at every iteration of a graph;
 //   * the producers of a graph hand their pieces to whichever of them arrives last (per-graph
-//     arrival counter: rows stored write-through and drained before the producer's ticket,
-//     agent-scope acquire by the last arriver before it reads them).  That work-group
+//     arrival counter: rows stored write-through and drained before the producer's ticket;
+//     the last arriver reads them past its vector cache).  That work-group
 //     normalises (nrm = ||Xnew||_2 in canonical order, X = Xnew / nrm) and, unless the graph
 //     has converged (max|X - Xprev| < tol) or used up its iterations, pushes the graph's R
 //     items of the next iteration into the queue;
-//   * the queue is a ring of 8-byte {generation, item} granules with a head and a tail ticket
+//   * the queue is a ring of 8-byte {lap tag, R, item} granules with a head and a tail ticket
 //     counter.  A consumer draws a ticket and polls ITS OWN slot until the granule of its
 //     generation appears (or until no graph is left), then clears the slot.  At most
 //     sum_g (items of g) <= capacity items are ever undrawn (a graph's next items are pushed only after
@@ -338,6 +428,11 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
   (((unsigned)(g) << 16) | ((unsigned)(i) << 8) | ((unsigned)(q) << 4) | (unsigned)(nb))
 #define MPM_MAX_COL_BLOCKS 8
 #define MPM_SPIN_LIMIT (1u << 21)
+// queue granule: lap tag (16 bits, never 0) | node count R of the item's graph (8 bits) | 0 (8 bits)
+// | item word (32 bits).  R travels with the item so that a consumer can address X at once.
+#define MPM_LAP_TAG(ticket, cap) ((unsigned)(((ticket) / (cap)) % 65535u) + 1u)
+#define MPM_GRANULE(tag, R, item) \
+  (((unsigned long long)(tag) << 48) | ((unsigned long long)(R) << 40) | (unsigned long long)(unsigned)(item))
 
 // Column blocks per row of an R-node graph.  Base rule: slab bytes / 2 MiB rounded up, so that
 // one large graph can occupy the whole device.  When the items in flight (graphs still
@@ -411,6 +506,20 @@ struct MpmQueue {
 #define SSTAMP(k) do {} while (0)
 #endif
 
+// Diagnostic build (-DGVAE_STREAM_TRACE): every item leaves one 64-byte record of 100 MHz
+// wall-clock stamps in a caller-supplied buffer (gvae_debug_trace):
+//   [0] item word | block << 32   [1] ticket drawn  [2] item received  [3] X loaded
+//   [4] rows streamed and stored  [5] arrival counted  [6] last arriver: next items pushed (else 0)
+//   [7] graph iteration's item count << 32 | rows of this item
+#ifdef GVAE_STREAM_TRACE
+__device__ unsigned long long *g_trace_buf;
+__device__ unsigned g_trace_cap;
+__device__ unsigned g_trace_n;
+#define TSTAMP(k) do { if (tid == 0) tr[k] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(k) do {} while (0)
+#endif
+
 __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAVES))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
@@ -420,27 +529,35 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
   extern __shared__ float lds[];
   __shared__ float red[16];
   __shared__ float s_nrm;
-  __shared__ int s_item, s_last, s_cont, s_base, s_nb;
+  __shared__ int s_item, s_R, s_last, s_cont, s_base, s_nb, s_done, s_alive;
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef GVAE_STREAM_STAMPS
   long long ss_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long ss_last = __builtin_readcyclecounter();
   int ss_items = 0, ss_lasts = 0;
 #endif
+#ifdef GVAE_STREAM_TRACE
+  unsigned long long tr[8];
+#endif
   for (;;) {
     SSTAMP(9);
+#ifdef GVAE_STREAM_TRACE
+    for (int k = 0; k < 8; ++k) tr[k] = 0;
+#endif
+    TSTAMP(1);
     // ---- draw a ticket and wait for its granule (one lane)
     if (tid == 0) {
       const unsigned ticket = (unsigned)__hip_atomic_fetch_add(Q_HEAD(q), 1, __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned slot = ticket % q.cap, want = ticket / q.cap + 1u;
+      const unsigned slot = ticket % q.cap, want = MPM_LAP_TAG(ticket, q.cap);
       int got = 0;
       unsigned item = MPM_NULL_ITEM;
       for (unsigned spins = 0;; ++spins) {
         const unsigned long long v =
             __hip_atomic_load(&q.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == want) {
+        if ((unsigned)(v >> 48) == want) {
           item = (unsigned)v;
+          s_R = (int)((v >> 40) & 0xFFu);
           got = 1;
           // free the slot for the ticket one lap later
           __hip_atomic_store(&q.slots[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -455,15 +572,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         }
         __builtin_amdgcn_s_sleep(16);
       }
-      // the item's graph state (X, iteration count) was written by another work-group
-      if (got) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_item = got ? (int)item : -2;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int item = s_item;
+    // the item is the same for every lane: say so, which keeps what derives from it in scalar
+    // registers (addresses, loop bounds)
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
     if (item == -2) break;
     SSTAMP(0);
+    TSTAMP(2);
 #ifdef GVAE_STREAM_STAMPS
     ++ss_items;
 #endif
@@ -471,27 +588,50 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       const int g = (unsigned)item >> 16, i0 = (item >> 8) & 0xFF, q_blk = (item >> 4) & 0xF;
       const int shape = item & 0xF;
       const int n_blk = mpm_shape_blocks(shape);              // column blocks per row i
-      const int R = Rarr[g];
+      const int R = __builtin_amdgcn_readfirstlane(s_R);
       const int R2 = R * R;
       const int RS = s_row_stride(R, layout);
       const int rows_here = min(mpm_shape_rows(shape), R - i0);
+      // issued ahead of the X loads so that one round trip covers them all: the offset of the
+      // graph's S block, and (one lane) what the last arriver of this iteration will need
+      const int64_t s_off_g = S_off[g];
+      int done_r = 0, alive_r = 0;
+      if (tid == 0) {
+        done_r = __hip_atomic_load(&iters_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alive_r = __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const int Aw_full = (R + n_blk - 1) / n_blk;
       const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
       float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
       float *T = lds + R * RS;    // R*R
-      float *nsrow = T + R2;      // R
+      float *nsrow = T + R2;      // rows_here * R
       float *Xg = X + g * strideX;
       float *Xn = Xnew + g * strideXnew;
+      // X was written by another work-group of this launch (write-through stores, drained
+      // before the item was pushed): read it past this CU's vector cache, which is the only
+      // cache another CU's stores do not reach
       for (int e = tid; e < R * RS; e += nt) {
         const int r = e / RS, c = e - r * RS;
-        Xs[e] = Xg[(int64_t)r * ldx + min(c, R - 1)];
+        Xs[e] = __hip_atomic_load(&Xg[(int64_t)r * ldx + min(c, R - 1)], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
       }
+      // S[i,i,a,a], the factor of X[i,a] in the update, for every row i of the item: a strided
+      // gather that shares the round trip of the X loads
+      const float *Sg = S + s_off_g;
+      for (int e = tid; e < rows_here * Aw; e += nt) {
+        const int ri = e / Aw, p = a0 + (e - ri * Aw), i = i0 + ri;
+        nsrow[ri * R + p] = Sg[((int64_t)i * R2 + (int64_t)i * R + p) * RS + p];
+      }
+      if (tid == 0) {
+        s_done = done_r;
+        s_alive = alive_r;
+      }
+      __syncthreads();
+      TSTAMP(3);
       for (int ri = 0; ri < rows_here; ++ri) {
         const int i = i0 + ri;
-        const float *slab = S + S_off[g] + (int64_t)i * R2 * RS;
-        // S[i,i,a,a], the factor of X[i,a] in the update
-        for (int p = a0 + tid; p < a0 + Aw; p += nt) nsrow[p] = slab[((int64_t)i * R + p) * RS + p];
-        __syncthreads();
+        const float *slab = Sg + (int64_t)i * R2 * RS;
+        const float *nsr = nsrow + ri * R;
         SSTAMP(1);
         if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
         else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
@@ -503,31 +643,32 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           const float et = column_sum(
               [&](int jj) { return jj == i ? 0.0f : T[jj * Aw + (p - a0)]; }, p, R);
           // write-through store (no release fence needed for a write-through payload)
-          __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsrow[p] + et, __ATOMIC_RELAXED,
+          __hip_atomic_store(&Xn[i * R + p], Xs[i * RS + p] * nsr[p] + et, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (ri + 1 < rows_here) __syncthreads();   // T and nsrow are rewritten for the next row
+        if (ri + 1 < rows_here) __syncthreads();   // T is rewritten for the next row
       }
       // publish this row: every storing wave drains its stores, then one lane takes a ticket
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       SSTAMP(3);
+      TSTAMP(4);
       if (tid == 0) {
         const int before = __hip_atomic_fetch_add(&q.arrive[g], rows_here, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (before + rows_here == R * n_blk) ? 1 : 0;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_last = last;
+        s_last = (before + rows_here == R * n_blk) ? 1 : 0;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       SSTAMP(4);
+      TSTAMP(5);
       if (s_last) {
 #ifdef GVAE_STREAM_STAMPS
         ++ss_lasts;
 #endif
         // ---- last arriver: normalise the graph
-        for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
+        // (the other producers' rows: write-through stores, read past the vector cache)
+        for (int e = tid; e < R2; e += nt)
+          T[e] = __hip_atomic_load(&Xn[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         SSTAMP(5);
         const int n8 = R2 & ~7;
@@ -558,14 +699,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         if (tid == 0) {
           float d = red[0];
           for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
-          const int done = __hip_atomic_load(&iters_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          // the iteration count and the number of live graphs were read when the item started
+          // (the count only changes here, once per iteration; the other is a heuristic input)
+          const int done = s_done + 1;
           __hip_atomic_store(&iters_done[g], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&q.arrive[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
           if (cont) {
-            const int alive =
-                __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int shape_next = mpm_item_shape(R, RS, alive, q.low, q.high);
+            const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high);
             s_nb = shape_next;
             s_base = __hip_atomic_fetch_add(Q_TAIL(q), mpm_shape_items(R, shape_next),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -581,8 +722,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           const int shape_next = s_nb, n_next = mpm_shape_items(R, shape_next);
           for (int p = tid; p < n_next; p += nt) {
             const unsigned t = base + (unsigned)p;
-            const unsigned long long gran = ((unsigned long long)(t / q.cap + 1u) << 32) |
-                                            mpm_shape_item(g, p, shape_next);
+            const unsigned long long gran =
+                MPM_GRANULE(MPM_LAP_TAG(t, q.cap), R, mpm_shape_item(g, p, shape_next));
             unsigned long long *sl = &q.slots[t % q.cap];
             // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
             // undrawn), so its consumer is polling this slot and frees it promptly
@@ -599,7 +740,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         } else if (tid == 0) {
           __hip_atomic_fetch_add(Q_REMAIN(q), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        TSTAMP(6);
       }
+#ifdef GVAE_STREAM_TRACE
+      if (tid == 0) {
+        const unsigned n = atomicAdd(&g_trace_n, 1u);
+        if (n < g_trace_cap) {
+          tr[0] = (unsigned)item | ((unsigned long long)blockIdx.x << 32);
+          tr[7] = ((unsigned long long)(R * n_blk) << 32) | (unsigned)rows_here;
+          for (int k = 0; k < 8; ++k) g_trace_buf[8ull * n + k] = tr[k];
+        }
+      }
+#endif
     }
     __syncthreads();  // s_item and the LDS buffers are free again
     SSTAMP(8);
@@ -618,7 +770,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
 // The slots beyond the total stay empty (zeroed by the host) until the tail reaches them.
 __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
                                                               const int32_t *__restrict__ Rarr,
-                                                              int n_graphs, int layout,
+                                                              int n_graphs, int r_max, int layout,
                                                               int32_t *__restrict__ iters_done) {
   __shared__ int s_part[1024];
   __shared__ int s_live[1024];
@@ -627,7 +779,8 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
   const int g_lo = min(tid * per, n_graphs), g_hi = min(g_lo + per, n_graphs);
   auto items_of = [&](int g, int &shape) {
     const int R = Rarr[g];
-    if (R <= 0) { shape = 0; return 0; }
+    if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
+    if (R <= 0 || R > r_max) { shape = 0; return 0; }
     shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high);
     return mpm_shape_items(R, shape);
   };
@@ -657,7 +810,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     int nb;
     const int n = items_of(g, nb);
     for (int k = 0; k < n; ++k)
-      q.slots[pos + k] = (1ull << 32) | mpm_shape_item(g, k, nb);
+      q.slots[pos + k] = MPM_GRANULE(1u, Rarr[g], mpm_shape_item(g, k, nb));
     pos += n;
   }
   if (tid == 1023) {
@@ -963,6 +1116,23 @@ using namespace gvae;
 
 extern "C" {
 
+#ifdef GVAE_STREAM_TRACE
+// diagnostic builds only: where the streamed MPM leaves its per-item records (cap records of 64 bytes)
+int gvae_debug_trace(void *d_buf, int cap) {
+  unsigned zero = 0, ucap = (unsigned)cap;
+  unsigned long long *b = (unsigned long long *)d_buf;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)) != hipSuccess) return GVAE_ELAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &ucap, sizeof(ucap)) != hipSuccess) return GVAE_ELAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero)) != hipSuccess) return GVAE_ELAUNCH;
+  return GVAE_OK;
+}
+int gvae_debug_trace_count(void) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
+
 int gvae_node_sim(const float *d_A, const float *d_P, const int32_t *d_R, int n_graphs, int ld,
                   int64_t stride, float *d_NS, void *stream) {
   GVAE_REQUIRE(d_A && d_P && d_R && d_NS, GVAE_EINVAL, "node_sim: null pointer");
@@ -1021,8 +1191,9 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                GVAE_ELIMIT, "mpm_stream: too many graphs (n_graphs=%d, r_max=%d)", n_graphs, r_max);
   GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
                "mpm_stream: unknown S layout %d", s_layout);
-  const size_t lds =
-      sizeof(float) * ((size_t)r_max * ((r_max + 3) & ~3) + (size_t)r_max * r_max + r_max);
+  // X (padded rows) | T | the diagonal factors of an item's rows (up to 8 rows of small graphs)
+  const size_t lds = sizeof(float) * ((size_t)r_max * ((r_max + 3) & ~3) + (size_t)r_max * r_max +
+                                      (size_t)(r_max > 256 ? r_max : 256));
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
   if (n_graphs == 0) return GVAE_OK;
@@ -1049,7 +1220,15 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                GVAE_ELAUNCH, "mpm_stream: memset failed");
   // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
   // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
-  const int nt = r_max >= 48 ? 1024 : 256;
+  int nt = r_max >= 48 ? 1024 : 256;
+  q.low = 256;
+  q.high = 2048;   // measured: 16-node graphs 3.0 -> 1.65 ms per 1024, 24-node 3.08 -> 2.67 ms per 512
+#ifdef GVAE_TUNE
+  // tuning builds only: launch shape and item-shape thresholds from the environment
+  if (const char *e = getenv("GVAE_MPM_NT")) nt = atoi(e);
+  if (const char *e = getenv("GVAE_MPM_LOW")) q.low = atoi(e);
+  if (const char *e = getenv("GVAE_MPM_HIGH")) q.high = atoi(e);
+#endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1060,10 +1239,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   // others leave, which only happens once every graph is finished, and then leave at once
   const int max_blocks = 2048 * 256 / nt;
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
-  q.low = 256;
-  q.high = 2048;   // measured: 16-node graphs 3.0 -> 1.65 ms per 1024, 24-node 3.08 -> 2.67 ms per 512
-  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, s_layout,
-                     d_iters_done);
+  hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
+                     s_layout, d_iters_done);
   {
     ProfileScope ps(F_MPM_ITER, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,

@@ -138,14 +138,18 @@ class TrainStep:
     loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
 
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
-                 world: int = 1, group=None, sync_bn_buffers: bool = True, engine=None) -> None:
+                 world: int = 1, group=None, sync_bn_buffers: bool = True, engine=None,
+                 force_collectives: bool = False) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
-        model's HIP engine (tests inject a CPU checker to exercise the collective pattern)."""
+        model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
+        `force_collectives`: issue the step's collectives even in a group of one rank (a
+        single-GPU rehearsal of the stream ordering between RCCL and the HIP kernels)."""
         self.model = model
         self._engine = engine
         self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
         self.world, self.group = world, group
         self.sync_bn_buffers = sync_bn_buffers
+        self.collectives = world > 1 or force_collectives
         flat = model.flat_parameters()
         self.grads = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
@@ -158,7 +162,7 @@ class TrainStep:
         """One optimisation step; returns a copy of [rec, kl, max_logit, logvar_max] (device).
         `eps` (B, z_dim) overrides the reparameterisation noise (tests)."""
         model = self.model
-        if self.world > 1 and self.sync_bn_buffers:
+        if self.collectives and self.sync_bn_buffers:
             # DDP's broadcast_buffers: every forward starts from rank 0's running statistics
             dist.broadcast(model.bn_state(), src=0, group=self.group)
         eng = self._engine if self._engine is not None else model._engine_for(batch)
@@ -167,7 +171,7 @@ class TrainStep:
         out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
                            model._pos_weight_dev(), True).clone()
         eng.backward(model.flat_parameters(), model._pos_weight_dev(), self.grads, 1.0, beta)
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
         self.t += 1
         eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
