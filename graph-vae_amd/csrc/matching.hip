@@ -352,9 +352,9 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
       case 1 * 8 + 1: return mpm_iter_body_v4<1, 1, D>(slab, R, RS, a0, Aw, Xs, T);
       case 2 * 8 + 1: return mpm_iter_body_v4<2, 1, D>(slab, R, RS, a0, Aw, Xs, T);
       case 3 * 8 + 1: return mpm_iter_body_v4<3, 1, D>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, D / 2>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, (D + 1) / 2>(slab, R, RS, a0, Aw, Xs, T);
       case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, D / 4>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4>(slab, R, RS, a0, Aw, Xs, T);
       case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
       default: break;
     }
@@ -438,8 +438,8 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // one large graph can occupy the whole device.  When the items in flight (graphs still
 // iterating x R x blocks) are fewer than `low`, the rows are cut finer: a nearly empty device
 // is bound by the latency of a graph's chain of iterations, and smaller pieces shorten the
-// streaming phase of each link (measured: worth it only below a few hundred items; every item
-// also costs about 12 ns of serialised queue traffic).  The result nb satisfies
+// streaming phase of each link (measured: worth it below about a thousand items; every item
+// costs a ticket, a 4 KiB X load and an arrival, each a memory round trip).  The result nb satisfies
 // nb == ceil(R / ceil(R / nb)), so a consumer recovers the block width from nb alone.
 __host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low) {
   const long long slab = 4LL * R * R * RS;
@@ -1221,8 +1221,10 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
   // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
   int nt = r_max >= 48 ? 1024 : 256;
-  q.low = 256;
-  q.high = 2048;   // measured: 16-node graphs 3.0 -> 1.65 ms per 1024, 24-node 3.08 -> 2.67 ms per 512
+  // measured on 256 graphs of 32 nodes with early stop: 2.77 ms at (1024, 4096) against 2.84 at
+  // (256, 2048); grouping rows at all: 16-node graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512
+  q.low = 1024;
+  q.high = 4096;
 #ifdef GVAE_TUNE
   // tuning builds only: launch shape and item-shape thresholds from the environment
   if (const char *e = getenv("GVAE_MPM_NT")) nt = atoi(e);
