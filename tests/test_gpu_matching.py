@@ -265,3 +265,39 @@ def test_argument_errors(hip):
         hip.mpm_fused(A, A, A, R, 200, A.clone())
     with pytest.raises(hip.GvaeHipError):
         hip.lsap(A, R, 200)
+
+
+@pytest.mark.parametrize("R", [1, 44, 70, 100, 131, 140])
+def test_stream_row_shapes_vs_oracle(hip, R):
+    """One case per row shape of the streaming loop (lanes per row x passes: 44 -> 8x2, 70 -> 8x3,
+    100 -> 8x4, 131 and 140 -> 16x3; 1 is the degenerate single row): three iterations of the
+    streamed MPM on the materialised tensor equal the S-free oracle bit for bit."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + R)
+    up = np.triu((rng.random((R, R)) < 0.4).astype(np.float32), 1)
+    A = up + up.T + np.eye(R, dtype=np.float32)
+    lg = np.triu(rng.normal(0, 1.0, (R, R)).astype(np.float32), 1)
+    P = (1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32)
+    Ad, Pd = torch.from_numpy(A[None]).to(dev), torch.from_numpy(P[None]).to(dev)
+    Rd = torch.tensor([R], dtype=torch.int32, device=dev)
+    NS = hip.node_sim(Ad, Pd, Rd)
+    S, S_off = hip.edge_sim(Ad, Pd, NS, Rd, [R], hip.S_PADDED)
+    X = hip.x0_uniform([R], R, dev)
+    done = hip.mpm_stream(S, S_off, Rd, R, X, 3, 1e-4, False, layout=hip.S_PADDED)
+    Xo, done_o = ora.mpm_sfree(A, P, None, 3, 1e-4, False)
+    assert int(done[0]) == done_o == 3
+    assert np.array_equal(X[0].cpu().numpy(), Xo)
+
+
+def test_stream_rejects_graph_larger_than_launch(hip):
+    """A node count above r_max is not run and is reported through the iteration counts."""
+    dev = torch.device("cuda:0")
+    Rh = [6, 9]
+    A = torch.eye(9, device=dev).repeat(2, 1, 1)
+    P = torch.full((2, 9, 9), 0.5, device=dev)
+    R = torch.tensor(Rh, dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    S, S_off = hip.edge_sim(A, P, NS, R, Rh, hip.S_PADDED)
+    X = hip.x0_uniform(Rh, 9, dev)
+    done = hip.mpm_stream(S, S_off, R, 8, X, 5, 1e-4, True, layout=hip.S_PADDED)   # r_max 8 < 9
+    assert (done < 0).all()
