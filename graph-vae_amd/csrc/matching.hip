@@ -95,6 +95,9 @@ __device__ __forceinline__ void edge_sim_body(const float *__restrict__ Pg,
   }
 }
 
+// floats reserved at the front of the dynamic LDS region of the MPM kernels for control words
+constexpr int kCtlFloats = 32;
+
 // row stride of a graph's S block: R floats (dense) or R rounded up to a multiple of 4
 __host__ __device__ __forceinline__ int s_row_stride(int R, int layout) {
   return layout == GVAE_S_PADDED ? ((R + 3) & ~3) : R;
@@ -526,10 +529,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
                                   float *__restrict__ Xnew, int64_t strideXnew, float tol,
                                   int early_stop, int iters, int layout, MpmQueue q,
                                   int32_t *__restrict__ iters_done) {
-  extern __shared__ float lds[];
-  __shared__ float red[16];
-  __shared__ float s_nrm;
-  __shared__ int s_item, s_R, s_last, s_cont, s_base, s_nb, s_done, s_alive;
+  // The control words live at the front of the dynamic region (kCtlFloats floats): a static
+  // __shared__ object would precede the dynamic region unpadded and push its base off the
+  // 16-byte alignment that the 128-bit LDS reads of X need (misaligned ones are replayed).
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float *red = lds_all;                                  // [16]
+  float &s_nrm = lds_all[16];
+  int *ctl = reinterpret_cast<int *>(lds_all + 17);
+  int &s_item = ctl[0], &s_R = ctl[1], &s_last = ctl[2], &s_cont = ctl[3], &s_base = ctl[4],
+      &s_nb = ctl[5], &s_done = ctl[6], &s_alive = ctl[7];
+  float *lds = lds_all + kCtlFloats;
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef GVAE_STREAM_STAMPS
   long long ss_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -903,10 +912,13 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
     int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float red[16];
-  __shared__ float s_nrm;
-  __shared__ int s_stop;
+  // control words at the front of the dynamic region (see mpm_stream_kernel): the 128-bit LDS
+  // reads below need its base 16-byte aligned, which a static __shared__ object would undo
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float *red = lds_all;                                  // [16]
+  float &s_nrm = lds_all[16];
+  int &s_stop = *reinterpret_cast<int *>(lds_all + 17);
+  float *lds = lds_all + kCtlFloats;
   const int g = blockIdx.x, tid = threadIdx.x;
   constexpr int nt = NT;
   const int R = Rarr[g];
@@ -959,7 +971,7 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
   const bool vec4 = (R & 3) == 0;
   int done = 0;
 #ifdef GVAE_FUSED_STAMPS
-  long long st_acc[5] = {0, 0, 0, 0, 0};
+  long long st_acc[5] = {0, 0, 0, 0, 0}, st_inner = 0;
   long long st_last = __builtin_readcyclecounter();
 #endif
   for (int it = 0; it < iters; ++it) {
@@ -967,6 +979,9 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
     // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b]  (>= 0; Pp[a,a] = 0).  A lane takes one column a
     // and four consecutive rows j at a time: per 4 values of b it reads one 16-byte piece of
     // Pp's row a and four (wave-broadcast) pieces of X.
+#ifdef GVAE_FUSED_STAMPS
+    const long long ti0 = __builtin_readcyclecounter();
+#endif
     for (int w = tid; w < R * JQ; w += nt) {
       const int jq = w / R, a = w - jq * R;
       const int j0 = jq * 4;
@@ -1005,6 +1020,9 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
       if (j0 + 2 < R) M[(j0 + 2) * R + a] = m2;
       if (j0 + 3 < R) M[(j0 + 3) * R + a] = m3;
     }
+#ifdef GVAE_FUSED_STAMPS
+    st_inner += __builtin_readcyclecounter() - ti0;
+#endif
     __syncthreads();
     STAMP(0);
     // phase 2: Xn[i,a] = Xprev[i,a]*NS[i,a] + sum_{j: A[i,j]} M[j,a]  (canonical column sums),
@@ -1086,8 +1104,8 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
   }
 #ifdef GVAE_FUSED_STAMPS
   if (g == 0 && tid == 0)
-    printf("fused stamps R=%d iters=%d: maxprod %lld  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
-           R, done, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
+    printf("fused stamps R=%d iters=%d: maxprod %lld (lane 0 without the barrier %lld)  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
+           R, done, st_acc[0], st_inner, st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
 #endif
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
@@ -1192,8 +1210,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
                "mpm_stream: unknown S layout %d", s_layout);
   // X (padded rows) | T | the diagonal factors of an item's rows (up to 8 rows of small graphs)
-  const size_t lds = sizeof(float) * ((size_t)r_max * ((r_max + 3) & ~3) + (size_t)r_max * r_max +
-                                      (size_t)(r_max > 256 ? r_max : 256));
+  const size_t lds = sizeof(float) * (kCtlFloats + (size_t)r_max * ((r_max + 3) & ~3) +
+                                      (size_t)r_max * r_max + (size_t)(r_max > 256 ? r_max : 256));
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
   if (n_graphs == 0) return GVAE_OK;
@@ -1262,7 +1280,7 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
                "mpm_fused: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "mpm_fused: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", n_graphs, r_max, ld, ldx);
-  const size_t lds = 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
+  const size_t lds = 4 * kCtlFloats + 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
                      4 * (size_t)r_max * ((r_max + 31) / 32);
   GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
                "mpm_fused: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", r_max, lds);

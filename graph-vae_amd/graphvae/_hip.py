@@ -175,7 +175,7 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
 
 def mpm_fused_supported(r_max: int) -> bool:
     """Whether the single-work-group fused MPM fits its LDS budget for this size."""
-    return r_max <= MAX_NODES_LDS and (12 * r_max * r_max + 16 * r_max
+    return r_max <= MAX_NODES_LDS and (128 + 12 * r_max * r_max + 16 * r_max
                                        + 4 * r_max * ((r_max + 31) // 32)) <= 159 * 1024
 
 
