@@ -130,17 +130,33 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
       }
       lowest = wave_min_f64(lowest);
       if (lowest == INFINITY) return 1;      // infeasible
-      int key = -1;
+      // columns at the minimum distance: usually exactly one, which the ballot names directly;
+      // only a tie needs the second wave-wide reduction over the selection keys
+      bool at_min[NCH];
+      unsigned long long m_at[NCH];
+      int n_at = 0;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (pos[c] >= 0 && spc[c] == lowest) {
-          const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
-          key = max(key, k);
-        }
+        at_min[c] = pos[c] >= 0 && spc[c] == lowest;
+        m_at[c] = __ballot(at_min[c]);
+        n_at += __popcll(m_at[c]);
       }
-      const int best = wave_max_i32(key);
-      const int L = __ffsll((long long)__ballot(key == best)) - 1;
-      const int j = (best & 1) * 64 + L;
+      int j;
+      if (n_at == 1) {
+        j = m_at[0] ? __ffsll((long long)m_at[0]) - 1 : 64 + __ffsll((long long)m_at[NCH - 1]) - 1;
+      } else {
+        int key = -1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (at_min[c]) {
+            const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
+            key = max(key, k);
+          }
+        }
+        const int best = wave_max_i32(key);
+        const int L = __ffsll((long long)__ballot(key == best)) - 1;
+        j = (best & 1) * 64 + L;
+      }
       minVal = lowest;
       const int rj = pick_i32<NCH>(row4col, j);
       const int pj = pick_i32<NCH>(pos, j);

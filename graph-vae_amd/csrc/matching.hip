@@ -908,7 +908,7 @@ __device__ __forceinline__ void cascade_chains(const float *__restrict__ Mcol, i
 // consecutive rows read 16-byte pieces conflict-free), X (R*R), M (R*R), A as bit rows.
 // NT = work-group size, KMAX = rows per lane (ceil(R / floor(NT / R)) <= KMAX must hold).
 template <int NT, int KMAX>
-__global__ __launch_bounds__(NT) void mpm_fused_kernel(
+__global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
     int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done) {
@@ -953,17 +953,25 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
   const int TJ = nt / R;
   const int ta = tid % R, tj = tid / R;
   const bool owner = tj < TJ;
-  float nsv[KMAX], xprev[KMAX];
+  // With 16 rows per lane (1024 threads, 128 registers each) the two arrays do not fit: that
+  // shape reads the node-similarity factor from global memory at its use and keeps the
+  // previous X in the caller's X buffer, rewritten every iteration (both stay in L2).
+  constexpr bool kRegs = KMAX <= 8;
+  constexpr int KR = kRegs ? KMAX : 1;
+  float nsv[KR], xprev[KR];
+  if constexpr (kRegs) {
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int i = tj + k * TJ;
-    nsv[k] = 0.f;
-    xprev[k] = 0.f;
-    if (owner && i < R) {
-      nsv[k] = NSg[(int64_t)i * ld + ta];
-      xprev[k] = Xg[(int64_t)i * ldx + ta];
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = tj + k * TJ;
+      nsv[k] = 0.f;
+      xprev[k] = 0.f;
+      if (owner && i < R) {
+        nsv[k] = NSg[(int64_t)i * ld + ta];
+        xprev[k] = Xg[(int64_t)i * ldx + ta];
+      }
     }
   }
+  auto ns_of = [&](int k, int i) { return kRegs ? nsv[kRegs ? k : 0] : NSg[(int64_t)i * ld + ta]; };
   __syncthreads();
 
   const int n8 = R2 & ~7;
@@ -1030,7 +1038,7 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
     if (owner) {
       const float *Mcol = M + ta;
       if (column_uses_cascade(ta, R)) {
-#pragma unroll
+#pragma unroll(kRegs ? KMAX / 4 : 1)
         for (int k0 = 0; k0 < KMAX; k0 += 4) {
           if (tj + k0 * TJ < R) {
             const uint32_t *br[4];
@@ -1041,7 +1049,8 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const int i = tj + (k0 + c) * TJ;
-              if (i < R) Xs[i * R + ta] = xprev[k0 + c] * nsv[k0 + c] + et[c];
+              // (Xs still holds the previous X here: each element is rewritten by its owner only)
+              if (i < R) Xs[i * R + ta] = Xs[i * R + ta] * ns_of(k0 + c, i) + et[c];
             }
           }
         }
@@ -1057,7 +1066,7 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
                   return ((ab[jj >> 5] >> (jj & 31)) & 1u) ? v : 0.0f;
                 },
                 R);
-            Xs[i * R + ta] = xprev[k] * nsv[k] + et;
+            Xs[i * R + ta] = Xs[i * R + ta] * ns_of(k, i) + et;
           }
         }
       }
@@ -1081,11 +1090,18 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
       const int i = tj + k * TJ;
       if (owner && i < R) {
         const float v = Xs[i * R + ta] / nrm;
-        const float d = fabsf(v - xprev[k]);
+        float prev;
+        if constexpr (kRegs) {
+          prev = xprev[k];
+          xprev[k] = v;
+        } else {
+          prev = Xg[(int64_t)i * ldx + ta];
+          Xg[(int64_t)i * ldx + ta] = v;
+        }
+        const float d = fabsf(v - prev);
         isnan_any |= (d != d);
         dmax = fmaxf(dmax, d);
         Xs[i * R + ta] = v;
-        xprev[k] = v;
       }
     }
     if (isnan_any) dmax = INFINITY;
@@ -1107,10 +1123,12 @@ __global__ __launch_bounds__(NT) void mpm_fused_kernel(
     printf("fused stamps R=%d iters=%d: maxprod %lld (lane 0 without the barrier %lld)  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
            R, done, st_acc[0], st_inner, st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
 #endif
+  if constexpr (kRegs) {
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int i = tj + k * TJ;
-    if (owner && i < R) Xg[(int64_t)i * ldx + ta] = xprev[k];
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = tj + k * TJ;
+      if (owner && i < R) Xg[(int64_t)i * ldx + ta] = xprev[k];
+    }
   }
   if (tid == 0) iters_done[g] = done;
 }
