@@ -470,8 +470,11 @@ __host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive,
   const long long slab = 4LL * R * R * RS;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R;
   int code = 0;
+  // (items of up to 128 KiB are short enough that half as many in flight keep the device busy)
   for (int rpi = 8, c = 11; rpi >= 2; rpi >>= 1, --c)
-    if (!code && slab * rpi <= (512LL << 10) && in_flight / rpi >= high && rpi <= R) code = c;
+    if (!code && slab * rpi <= (512LL << 10) && rpi <= R &&
+        in_flight / rpi >= (slab * rpi <= (128LL << 10) ? high / 2 : high))
+      code = c;
   return code ? code : mpm_col_blocks(R, RS, alive, low);
 }
 __host__ __device__ __forceinline__ int mpm_shape_blocks(int code) { return code <= 8 ? code : 1; }
