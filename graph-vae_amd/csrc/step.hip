@@ -212,6 +212,50 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(
 
 using namespace gvae;
 
+// Sampler: thresholded adjacency of generated graphs (reference experiments/sample.py:58-73).
+// One work-group per sample.  A node exists when sigmoid(node logit) > th_node; the edge logit
+// of a pair with a missing end point, and of the diagonal, is replaced by -10 before the
+// sigmoid, exactly as the reference does, so the bit is sigmoid(value) > th_edge in every case.
+__global__ __launch_bounds__(256) void sample_adj_kernel(const float *__restrict__ vec,
+                                                         const float *__restrict__ node, int N,
+                                                         float th_edge, float th_node,
+                                                         uint8_t *__restrict__ adj,
+                                                         uint8_t *__restrict__ exists,
+                                                         int32_t *__restrict__ count) {
+  __shared__ uint8_t ex[1024];
+  __shared__ int s_cnt;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int64_t U = (int64_t)N * (N - 1) / 2;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int c = tid; c < N; c += 256) {
+    const float p = 1.0f / (1.0f + expf(-node[(int64_t)g * N + c]));
+    const uint8_t e = p > th_node ? 1 : 0;
+    ex[c] = e;
+    exists[(int64_t)g * N + c] = e;
+    mine += e;
+  }
+  if (mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (tid == 0) count[g] = s_cnt;
+  const float p_off = 1.0f / (1.0f + expf(10.0f));      // sigmoid(-10)
+  const uint8_t bit_off = p_off > th_edge ? 1 : 0;
+  const float *vg = vec + g * U;
+  uint8_t *ag = adj + (int64_t)g * N * N;
+  for (int e = tid; e < N * N; e += 256) {
+    const int r = e / N, c = e - r * N;
+    uint8_t b = bit_off;
+    if (r != c && ex[r] && ex[c]) {
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int64_t pair = (int64_t)lo * N - (int64_t)lo * (lo + 1) / 2 + (hi - lo - 1);
+      b = 1.0f / (1.0f + expf(-vg[pair])) > th_edge ? 1 : 0;
+    }
+    ag[e] = b;
+  }
+}
+
+
 extern "C" {
 
 int64_t gvae_param_layout(const gvae_dims *d, int64_t *offsets, int64_t *sizes) {
@@ -409,6 +453,36 @@ int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which
     default: return set_error(GVAE_EINVAL, "read_debug: unknown buffer %d", which);
   }
   return GVAE_OK;
+}
+
+static inline int64_t pad4f(int64_t x) { return (x + 3) & ~3LL; }
+
+int64_t gvae_sample_ws_bytes(const gvae_dims *d, int n) {
+  if (!d || n <= 0) return 0;
+  return 4 * 2 * pad4f((int64_t)n * d->H);
+}
+
+int gvae_sample_decode(const gvae_dims *d, const float *d_params, const float *d_z, int n,
+                       float th_edge, float th_node, float *d_edge_logits, float *d_node_logits,
+                       uint8_t *d_adj, uint8_t *d_exists, int32_t *d_count, void *d_ws,
+                       void *stream) {
+  GVAE_REQUIRE(d && d_params && d_z && d_edge_logits && d_node_logits && d_adj && d_exists &&
+                   d_count && d_ws,
+               GVAE_EINVAL, "sample_decode: null pointer");
+  GVAE_REQUIRE(n > 0 && n <= 65535 && d->N >= 2 && d->N <= 1024, GVAE_EINVAL,
+               "sample_decode: bad sizes (n=%d N=%d)", n, d->N);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = d->H, Z = d->Z, N = d->N;
+  const int U = N * (N - 1) / 2;
+  const Params P = bind(d, d_params);
+  float *he = (float *)d_ws, *hn = he + pad4f((int64_t)n * H);
+  TRY(linear_fwd(d_z, Z, P.p[GVAE_P_DE1_W], P.p[GVAE_P_DE1_B], he, n, H, Z, 1, s));
+  TRY(linear_fwd(he, H, P.p[GVAE_P_DE2_W], P.p[GVAE_P_DE2_B], d_edge_logits, n, U, H, 0, s));
+  TRY(linear_fwd(d_z, Z, P.p[GVAE_P_DN1_W], P.p[GVAE_P_DN1_B], hn, n, H, Z, 1, s));
+  TRY(linear_fwd(hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], d_node_logits, n, N, H, 0, s));
+  hipLaunchKernelGGL(sample_adj_kernel, dim3(n), dim3(256), 0, s, d_edge_logits, d_node_logits, N,
+                     th_edge, th_node, d_adj, d_exists, d_count);
+  return check_launch("sample_decode");
 }
 
 int64_t gvae_adam_ws_bytes(void) { return NORM_BLOCKS * sizeof(double); }

@@ -56,8 +56,39 @@ def _bind():
     L.gvae_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                  c_void_p, c_void_p]
+    L.gvae_sample_ws_bytes.argtypes = [POINTER(Dims), c_int]
+    L.gvae_sample_ws_bytes.restype = c_int64
+    L.gvae_sample_decode.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_int, c_float, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]
     _bound = True
     return L
+
+
+def sample_decode(F: int, H: int, Z: int, N: int, flat_params: torch.Tensor, z: torch.Tensor,
+                  th_edge: float = 0.5, th_node: float = 0.5) -> dict:
+    """Decoder pass of the sampler on the GPU (gvae_sample_decode): z (n, Z) -> edge logits
+    (n, N(N-1)/2), node logits (n, N), adjacency bits (n, N, N) uint8, node-existence bits
+    (n, N) uint8 and the number of existing nodes per sample (n,) int32."""
+    L = _bind()
+    if not (flat_params.is_cuda and z.is_cuda):
+        raise _hip.GvaeHipError("sample_decode needs device tensors (no CPU fallback)")
+    if z.dim() != 2 or z.shape[1] != Z or z.dtype != torch.float32:
+        raise ValueError(f"z must be (n, {Z}) float32, got {tuple(z.shape)} {z.dtype}")
+    z = z.contiguous()
+    n, dev, d = z.shape[0], z.device, Dims(F, H, Z, N)
+    edge = torch.empty(n, N * (N - 1) // 2, dtype=torch.float32, device=dev)
+    node = torch.empty(n, N, dtype=torch.float32, device=dev)
+    adj = torch.empty(n, N, N, dtype=torch.uint8, device=dev)
+    exists = torch.empty(n, N, dtype=torch.uint8, device=dev)
+    count = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.gvae_sample_ws_bytes(ctypes.byref(d), n), dtype=torch.uint8, device=dev)
+    _hip._check(L.gvae_sample_decode(ctypes.byref(d), flat_params.data_ptr(), z.data_ptr(), n,
+                                     float(th_edge), float(th_node), edge.data_ptr(), node.data_ptr(),
+                                     adj.data_ptr(), exists.data_ptr(), count.data_ptr(),
+                                     ws.data_ptr(), _hip._stream()))
+    return {"edge_logits": edge, "node_logits": node, "adj": adj, "node_exists": exists,
+            "num_nodes": count}
 
 
 def param_layout(F: int, H: int, Z: int, N: int):

@@ -7,6 +7,7 @@ Drop-in surface (reference graphvae/models/model.py):
   ._edge_sim_tensor(A, B) -> (R,R,R,R)                                  :171-216
   ._mpm(X0, S, iters=50, tol=1e-4, early_stop=True) -> (R,R)            :247-276
   ._reparam(mu, logvar), vec_to_adj(vec, N, diag=False), deg_sim(d1, d2)
+  .sample_decode(z, th_edge, th_node): the sampler's decoder loop as one call  (experiments/sample.py:50-73)
 State-dict keys are the reference's (conv{1,2}.{bias,lin.weight}, bn{1,2}.*, mu.*,
 logvar.*, dec_edge.{0,2}.*, dec_node.{0,2}.*, pos_weight_global), so checkpoints move
 between the two implementations.
@@ -319,6 +320,17 @@ class GraphVAE(nn.Module):
                 bn.num_batches_tracked += batch.num_graphs
         return {"rec": rec, "kl": kl, "loss": rec + kl, "max_logit": max_logit,
                 "logvar_max": logvar_max}
+
+    @torch.no_grad()
+    def sample_decode(self, z: torch.Tensor, th_edge: float = 0.5, th_node: float = 0.5) -> dict:
+        """Batched decoder pass of the sampler (reference experiments/sample.py:50-73) in one
+        library call: logits of `dec_edge` / `dec_node`, thresholded adjacency (dummy rows,
+        dummy columns and the diagonal suppressed), node-existence mask and node counts."""
+        from ..engine import sample_decode
+        if not self._flat.is_cuda:
+            raise _hip.GvaeHipError("GraphVAE runs on the GPU only: move the model with .to('cuda')")
+        return sample_decode(self.in_dim, self.hid_dim, self.z_dim, self.max_nodes, self._flat,
+                             z.to(self._flat.device, torch.float32), th_edge, th_node)
 
     def last_permutations(self) -> torch.Tensor:
         """perm_full of every graph of the most recent forward, (B, max_nodes) int64."""

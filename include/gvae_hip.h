@@ -209,6 +209,18 @@ int gvae_adam_step(float *d_params, const float *d_grads, float *d_m, float *d_v
                    float grad_scale, float clip_max, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t step, void *d_ws, float *d_norm_out, void *stream);
 
+/* Decoder pass of the sampler; replaces the per-sample loop of experiments/sample.py:50-73:
+ * edge logits = dec_edge(z) (n, N(N-1)/2), node logits = dec_node(z) (n, N); a node exists
+ * when sigmoid(node logit) > th_node; adjacency bit (r,c) = sigmoid(v) > th_edge with
+ * v = the pair's edge logit, or -10 on the diagonal and where an end point does not exist.
+ * Outputs: both logit matrices, d_adj (n,N,N) bytes 0/1, d_exists (n,N) bytes 0/1,
+ * d_count (n) = existing nodes per sample.  d_ws: gvae_sample_ws_bytes(d, n) bytes. */
+int64_t gvae_sample_ws_bytes(const gvae_dims *d, int n);
+int gvae_sample_decode(const gvae_dims *d, const float *d_params, const float *d_z, int n,
+                       float th_edge, float th_node, float *d_edge_logits, float *d_node_logits,
+                       uint8_t *d_adj, uint8_t *d_exists, int32_t *d_count, void *d_ws,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -477,20 +477,87 @@ def gen_rho(ref, out: Path):
              pos_weight=model.pos_weight_global.numpy())
 
 
+def gen_sampler(ref, out: Path):
+    """The reference sampler (experiments/sample.py `main`) run on a seeded checkpoint: the
+    graphs it writes, for two threshold pairs, with the latent vectors it drew and the
+    decoder logits of the same model."""
+    import contextlib
+    import importlib.util
+    import io
+    import tempfile
+
+    import networkx as nx
+    import yaml
+
+    spec = importlib.util.spec_from_file_location("ref_sample", REF_ROOT + "/experiments/sample.py")
+    smod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(smod)
+    F, H, Z, N, num, seed = 1, 16, 8, 12, 6, 3
+    torch.manual_seed(7)
+    model = ref.GraphVAE(F, H, Z, N)
+    with torch.no_grad():                      # spread the logits so that both thresholds bite
+        for name, p in model.named_parameters():
+            if name.startswith("dec_"):
+                p.mul_(2.5) if p.dim() == 2 else p.uniform_(-0.5, 0.5)
+    store = {"dims": np.array([F, H, Z, N, num, seed], dtype=np.int64)}
+    for k, v in model.state_dict().items():
+        store[f"state/{k}"] = v.detach().numpy().copy()
+    with tempfile.TemporaryDirectory() as td:
+        run = Path(td)
+        torch.save(model.state_dict(), run / "graphvae_ddp.pt")
+        yaml.safe_dump({"in_dim": F, "hid_dim": H, "z_dim": Z, "max_nodes": N, "pool": "sum"},
+                       open(run / "params.yaml", "w"))
+        for tag, (th_e, th_n) in (("a", (0.5, 0.5)), ("b", (0.3, 0.6))):
+            drawn = []
+            orig = torch.randn
+
+            def spy(*a, **k):
+                t = orig(*a, **k)
+                drawn.append(t.detach().clone())
+                return t
+
+            torch.randn = spy
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    smod.main(run, num, th_e, th_n, "cpu", seed)
+            finally:
+                torch.randn = orig
+            z = [t for t in drawn if tuple(t.shape) == (num, Z)][-1]
+            store[f"{tag}/th"] = np.array([th_e, th_n], dtype=np.float64)
+            store[f"{tag}/z"] = z.numpy()
+            n_edges = 0
+            for i in range(num):
+                g = nx.read_gml(run / "samples_fixed" / f"sample_{i}.gml", label="label")
+                store[f"{tag}/nodes{i}"] = np.array(sorted(int(v) for v in g.nodes()), dtype=np.int64)
+                e = sorted((min(int(u), int(v)), max(int(u), int(v))) for u, v in g.edges())
+                store[f"{tag}/edges{i}"] = np.array(e, dtype=np.int64).reshape(-1, 2)
+                n_edges += len(e)
+            with torch.no_grad():
+                store[f"{tag}/edge_logits"] = model.dec_edge(z).numpy()
+                store[f"{tag}/node_logits"] = model.dec_node(z).numpy()
+            print(f"G9 sampler {tag}: th=({th_e},{th_n}) {n_edges} edges over {num} samples")
+    np.savez_compressed(out / "g9_sampler.npz", **store)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(Path(__file__).resolve().parents[1] / "tests" / "golden"))
+    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler)")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
     ref = import_reference()
+    if args.only == "sampler":
+        gen_sampler(ref, out)
+        return
     gen_forward_test(ref, out)
     gen_reduction_orders(out)
     gen_lsap(out)
     gen_rho(ref, out)
     gen_forward(ref, out)
     gen_matching(ref, out)
+    gen_sampler(ref, out)
 
 
 if __name__ == "__main__":
