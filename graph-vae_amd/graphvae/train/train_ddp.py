@@ -138,10 +138,15 @@ class TrainStep:
     loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
 
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
-                 world: int = 1, group=None, sync_bn_buffers: bool = True, engine=None,
+                 world: int = 1, group=None, sync_bn_buffers: bool = False, engine=None,
                  force_collectives: bool = False) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
         model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
+        `sync_bn_buffers`: broadcast rank 0's BatchNorm running statistics before every forward,
+        as DDP's broadcast_buffers does.  Training forwards never read them (batch statistics
+        are used) and rank 0's copy depends on rank 0's batches only, so by default the
+        broadcast is left to `sync_buffers()`, which the trainer calls before validation and
+        before saving: same statistics wherever they are read, one collective fewer per step.
         `force_collectives`: issue the step's collectives even in a group of one rank (a
         single-GPU rehearsal of the stream ordering between RCCL and the HIP kernels)."""
         self.model = model
@@ -156,6 +161,11 @@ class TrainStep:
         self.v = torch.zeros_like(flat)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.t = 0
+
+    def sync_buffers(self) -> None:
+        """Every rank takes rank 0's BatchNorm running statistics."""
+        if self.collectives:
+            dist.broadcast(self.model.bn_state(), src=0, group=self.group)
 
     def __call__(self, batch: DenseGraphBatch, beta: float, lr_scale: float,
                  eps: torch.Tensor | None = None) -> torch.Tensor:
@@ -313,6 +323,7 @@ def _ddp_worker(rank: int, world: int, args) -> None:
             dist.all_reduce(tot_tr, op=dist.ReduceOp.SUM)
         mean_tr = tot_tr.item() / max(1, len(dl_tr)) / world
 
+        step_fn.sync_buffers()          # validation reads the running statistics: rank 0's, everywhere
         model.eval()
         acc.zero_()
         with torch.no_grad():
