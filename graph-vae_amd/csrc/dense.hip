@@ -28,13 +28,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // These GEMMs are small and latency-bound (a few K-tiles per work-group), so a tile's global
 // loads (16 + 16 scalars per lane) are all issued back to back: one memory round trip per
 // 64-deep K-tile; long K is cut with split-K on the host side so that the chip is filled.
-__global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
+__device__ __forceinline__ void gemm_tile(const GemmDesc &d, int bx, int by, int z) {
   __shared__ float As[GT_K][GT_LD];
   __shared__ float Bs[GT_K][GT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
-  const int z = blockIdx.z;
+  const int m0 = by * GT_M, n0 = bx * GT_N;
   const float *A = d.A, *B = d.B;
   float *C = d.C;
   int k_begin = 0, k_end = d.K;
@@ -100,8 +99,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
   }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDesc d) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
+  gemm_tile(d, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent GEMMs in one launch: blockIdx.z runs over the members' z ranges
+// (batch or split index), the x/y extent is the largest member's and the other members'
+// surplus tiles leave at once.  The step's contractions are small (a few to a few dozen
+// tiles each), so members that do not depend on each other fill the chip together instead
+// of one after the other.
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup g) {
+  int k = 0;
+  while (k + 1 < g.n && (int)blockIdx.z >= g.z_begin[k + 1]) ++k;
+  if ((int)blockIdx.x >= g.tiles_x[k] || (int)blockIdx.y >= g.tiles_y[k]) return;
+  gemm_tile(g.d[k], blockIdx.x, blockIdx.y, blockIdx.z - g.z_begin[k]);
+}
+
+__device__ __forceinline__ void splitk_reduce(const GemmDesc &d, int64_t e) {
   if (e >= (int64_t)d.M * d.N) return;
   const int row = e / d.N, col = e - (int64_t)row * d.N;
   float v = 0.0f;
@@ -110,6 +124,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDesc d) {
   if (d.accumulate) v += d.C[row * d.c_rs + col];
   if (d.relu) v = fmaxf(v, 0.0f);
   d.C[row * d.c_rs + col] = v;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDesc d) {
+  splitk_reduce(d, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(GemmGroup g) {
+  const GemmDesc &d = g.d[blockIdx.y];
+  if (d.splits > 1) splitk_reduce(d, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 int launch_gemm(const GemmDesc &d, hipStream_t s) {
@@ -125,6 +148,60 @@ int launch_gemm(const GemmDesc &d, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
   }
   return check_launch("gemm");
+}
+
+int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk_floats,
+                      hipStream_t s) {
+  GVAE_REQUIRE(descs && n >= 1 && n <= GEMM_GROUP_MAX, GVAE_EINVAL, "gemm group: bad size %d", n);
+  // every split member gets its own stretch of the split-K workspace; a group that does not
+  // fit (or has a single member) runs as individual launches
+  int64_t used = 0;
+  bool fits = n > 1;
+  for (int k = 0; k < n; ++k) {
+    if (descs[k].splits > 1) {
+      descs[k].splitk_ws = splitk_base + used;
+      used += (((int64_t)descs[k].splits * descs[k].M * descs[k].N) + 63) & ~63LL;
+    }
+  }
+  if (used > splitk_floats) fits = false;
+  if (!fits) {
+    for (int k = 0; k < n; ++k) {
+      if (descs[k].splits > 1) descs[k].splitk_ws = splitk_base;
+      const int rc = launch_gemm(descs[k], s);
+      if (rc) return rc;
+    }
+    return GVAE_OK;
+  }
+  GemmGroup g;
+  g.n = n;
+  int gx = 0, gy = 0, gz = 0;
+  int64_t max_mn = 0;
+  bool any_split = false;
+  for (int k = 0; k < n; ++k) {
+    const GemmDesc &d = descs[k];
+    GVAE_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, GVAE_EINVAL,
+                 "gemm group: bad descriptor %d (M=%d N=%d K=%d batch=%d)", k, d.M, d.N, d.K, d.batch);
+    GVAE_REQUIRE(d.splits == 1 || d.batch == 1, GVAE_EINVAL, "gemm group: split-K needs batch == 1");
+    g.d[k] = d;
+    g.tiles_x[k] = ceil_div(d.N, GT_N);
+    g.tiles_y[k] = ceil_div(d.M, GT_M);
+    g.z_begin[k] = gz;
+    gz += d.splits > 1 ? d.splits : d.batch;
+    gx = g.tiles_x[k] > gx ? g.tiles_x[k] : gx;
+    gy = g.tiles_y[k] > gy ? g.tiles_y[k] : gy;
+    if (d.splits > 1) {
+      any_split = true;
+      const int64_t mn = (int64_t)d.M * d.N;
+      max_mn = mn > max_mn ? mn : max_mn;
+    }
+  }
+  for (int k = n; k <= GEMM_GROUP_MAX; ++k) g.z_begin[k] = gz;
+  GVAE_REQUIRE(gy <= 65535 && gz <= 65535, GVAE_ELIMIT, "gemm group: grid too large");
+  hipLaunchKernelGGL(gemm_group_kernel, dim3(gx, gy, gz), dim3(256), 0, s, g);
+  if (any_split)
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)((max_mn + 255) / 256), n), dim3(256),
+                       0, s, g);
+  return check_launch("gemm group");
 }
 
 // ---------------------------------------------------------------------------

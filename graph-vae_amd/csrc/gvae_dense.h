@@ -25,6 +25,19 @@ struct GemmDesc {
 };
 int launch_gemm(const GemmDesc &d, hipStream_t s);
 
+// Up to GEMM_GROUP_MAX GEMMs that do not depend on each other, in one launch (plus one
+// split-K reduction launch if any member is split).  launch_gemm_group hands each split
+// member its own part of the workspace (`splitk_floats` floats at `splitk_base`).
+#define GEMM_GROUP_MAX 4
+struct GemmGroup {
+  GemmDesc d[GEMM_GROUP_MAX];
+  int n = 0;
+  int z_begin[GEMM_GROUP_MAX + 1];
+  int tiles_x[GEMM_GROUP_MAX], tiles_y[GEMM_GROUP_MAX];
+};
+int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk_floats,
+                      hipStream_t s);
+
 int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
                         float *Ahat, hipStream_t s);
 // BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics

@@ -961,6 +961,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   // previous X in the caller's X buffer, rewritten every iteration (both stay in L2).
   constexpr bool kRegs = KMAX <= 8;
   constexpr int KR = kRegs ? KMAX : 1;
+  constexpr int kChainUnroll = kRegs ? KMAX / 4 : 1;
   float nsv[KR], xprev[KR];
   if constexpr (kRegs) {
 #pragma unroll
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     if (owner) {
       const float *Mcol = M + ta;
       if (column_uses_cascade(ta, R)) {
-#pragma unroll(kRegs ? KMAX / 4 : 1)
+#pragma unroll kChainUnroll
         for (int k0 = 0; k0 < KMAX; k0 += 4) {
           if (tj + k0 * TJ < R) {
             const uint32_t *br[4];

@@ -38,6 +38,7 @@ struct Workspace {
   float *dvec, *dnode, *dhe, *dhn, *dz, *dmu, *dlv, *dgvec, *dAct, *dY, *dH0;
   float *dgam_p, *dbet_p, *dbias_p;
   float *splitk;
+  int64_t splitk_floats;
   int32_t *status;
   char *mpm_ws;
   int64_t bytes;
@@ -75,7 +76,8 @@ static Workspace carve(const gvae_dims *d, int B, char *base) {
   int64_t mn = U * H;
   const int64_t cand[] = {(int64_t)B * H, H * H, H * F, N * H, Z * H, (int64_t)B * Z};
   for (int64_t c : cand) mn = c > mn ? c : mn;
-  w.splitk = take(512 * 4096 + mn);
+  w.splitk_floats = GEMM_GROUP_MAX * (512 * 4096 + mn);   // room for a whole group of split GEMMs
+  w.splitk = take(w.splitk_floats);
   w.status = reinterpret_cast<int32_t *>(take(B));
   w.mpm_ws = reinterpret_cast<char *>(take((gvae_mpm_stream_ws_bytes(B, (int)N) + 3) / 4));
   w.bytes = off;
@@ -106,35 +108,47 @@ static int pick_splits(int M, int N, int K) {
 }
 
 // C (M x N) = A (M x K, row-major lda) * W^T, W (N x K) row-major  [+bias][relu]
-static int linear_fwd(const float *A, int64_t lda, const float *W, const float *bias, float *C, int M,
-                      int N, int K, int relu, hipStream_t s) {
+static GemmDesc desc_linear_fwd(const float *A, int64_t lda, const float *W, const float *bias,
+                                float *C, int M, int N, int K, int relu) {
   GemmDesc g;
   g.A = A; g.a_rs = lda; g.a_cs = 1;
   g.B = W; g.b_rs = 1; g.b_cs = K;
   g.C = C; g.c_rs = N; g.bias = bias; g.M = M; g.N = N; g.K = K; g.relu = relu;
-  return launch_gemm(g, s);
+  return g;
 }
 // dA (M x K) (+)= dC (M x N) * W, W (N x K) row-major
-static int linear_bwd_input(const float *dC, const float *W, float *dA, int M, int N, int K,
-                            int accumulate, float *splitk, hipStream_t s) {
+static GemmDesc desc_linear_bwd_input(const float *dC, const float *W, float *dA, int M, int N, int K,
+                                      int accumulate, float *splitk) {
   GemmDesc g;
   g.A = dC; g.a_rs = N; g.a_cs = 1;
   g.B = W; g.b_rs = K; g.b_cs = 1;
   g.C = dA; g.c_rs = K; g.M = M; g.N = K; g.K = N; g.accumulate = accumulate;
   g.splits = pick_splits(M, K, N);
   g.splitk_ws = splitk;
-  return launch_gemm(g, s);
+  return g;
 }
 // dW (N x K) = dC^T (N x M) * A (M x K)
-static int linear_bwd_weight(const float *dC, const float *A, int64_t lda, float *dW, int M, int N,
-                             int K, float *splitk, hipStream_t s) {
+static GemmDesc desc_linear_bwd_weight(const float *dC, const float *A, int64_t lda, float *dW, int M,
+                                       int N, int K, float *splitk) {
   GemmDesc g;
   g.A = dC; g.a_rs = 1; g.a_cs = N;
   g.B = A; g.b_rs = lda; g.b_cs = 1;
   g.C = dW; g.c_rs = K; g.M = N; g.N = K; g.K = M;
   g.splits = pick_splits(N, K, M);
   g.splitk_ws = splitk;
-  return launch_gemm(g, s);
+  return g;
+}
+static int linear_fwd(const float *A, int64_t lda, const float *W, const float *bias, float *C, int M,
+                      int N, int K, int relu, hipStream_t s) {
+  return launch_gemm(desc_linear_fwd(A, lda, W, bias, C, M, N, K, relu), s);
+}
+static int linear_bwd_input(const float *dC, const float *W, float *dA, int M, int N, int K,
+                            int accumulate, float *splitk, hipStream_t s) {
+  return launch_gemm(desc_linear_bwd_input(dC, W, dA, M, N, K, accumulate, splitk), s);
+}
+static int linear_bwd_weight(const float *dC, const float *A, int64_t lda, float *dW, int M, int N,
+                             int K, float *splitk, hipStream_t s) {
+  return launch_gemm(desc_linear_bwd_weight(dC, A, lda, dW, M, N, K, splitk), s);
 }
 // Y[b] (N x H) = Ahat[b] (N x N) * X[b] (N x H)
 static int aggregate(const float *Ahat, const float *X, float *Y, int B, int N, int H, hipStream_t s) {
@@ -321,14 +335,25 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
   }
   TRY(launch_pool_fwd(w.H2, d_n_x, d_R, B, N, H, w.gvec, s));
   // heads + reparameterisation (model.py:298-299)
-  TRY(linear_fwd(w.gvec, H, P.p[GVAE_P_MU_W], P.p[GVAE_P_MU_B], w.mu, B, Z, H, 0, s));
-  TRY(linear_fwd(w.gvec, H, P.p[GVAE_P_LV_W], P.p[GVAE_P_LV_B], w.lvraw, B, Z, H, 0, s));
+  // (contractions that do not depend on each other go out as one grouped launch)
+  {
+    GemmDesc heads[2] = {
+        desc_linear_fwd(w.gvec, H, P.p[GVAE_P_MU_W], P.p[GVAE_P_MU_B], w.mu, B, Z, H, 0),
+        desc_linear_fwd(w.gvec, H, P.p[GVAE_P_LV_W], P.p[GVAE_P_LV_B], w.lvraw, B, Z, H, 0)};
+    TRY(launch_gemm_group(heads, 2, w.splitk, w.splitk_floats, s));
+  }
   TRY(launch_reparam_fwd(w.mu, w.lvraw, d_eps, B, Z, w.z, s));
   // decoder (model.py:302-303)
-  TRY(linear_fwd(w.z, Z, P.p[GVAE_P_DE1_W], P.p[GVAE_P_DE1_B], w.he, B, H, Z, 1, s));
-  TRY(linear_fwd(w.he, H, P.p[GVAE_P_DE2_W], P.p[GVAE_P_DE2_B], w.vec, B, U, H, 0, s));
-  TRY(linear_fwd(w.z, Z, P.p[GVAE_P_DN1_W], P.p[GVAE_P_DN1_B], w.hn, B, H, Z, 1, s));
-  TRY(linear_fwd(w.hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], w.node, B, N, H, 0, s));
+  {
+    GemmDesc l1[2] = {
+        desc_linear_fwd(w.z, Z, P.p[GVAE_P_DE1_W], P.p[GVAE_P_DE1_B], w.he, B, H, Z, 1),
+        desc_linear_fwd(w.z, Z, P.p[GVAE_P_DN1_W], P.p[GVAE_P_DN1_B], w.hn, B, H, Z, 1)};
+    TRY(launch_gemm_group(l1, 2, w.splitk, w.splitk_floats, s));
+    GemmDesc l2[2] = {
+        desc_linear_fwd(w.he, H, P.p[GVAE_P_DE2_W], P.p[GVAE_P_DE2_B], w.vec, B, U, H, 0),
+        desc_linear_fwd(w.hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], w.node, B, N, H, 0)};
+    TRY(launch_gemm_group(l2, 2, w.splitk, w.splitk_floats, s));
+  }
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
     hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
@@ -382,29 +407,41 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   auto G = [&](int i) { return d_grads + off[i]; };
 
   TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight, c_rec, d_up, w.dvec, w.dnode, s));
-  // edge head
-  TRY(linear_bwd_weight(w.dvec, w.he, H, G(GVAE_P_DE2_W), B, U, H, w.splitk, s));
+  // edge and node heads, layer by layer: the four contractions of a layer are independent
+  {
+    GemmDesc l2[4] = {
+        desc_linear_bwd_weight(w.dvec, w.he, H, G(GVAE_P_DE2_W), B, U, H, nullptr),
+        desc_linear_bwd_input(w.dvec, P.p[GVAE_P_DE2_W], w.dhe, B, U, H, 0, nullptr),
+        desc_linear_bwd_weight(w.dnode, w.hn, H, G(GVAE_P_DN2_W), B, N, H, nullptr),
+        desc_linear_bwd_input(w.dnode, P.p[GVAE_P_DN2_W], w.dhn, B, N, H, 0, nullptr)};
+    TRY(launch_gemm_group(l2, 4, w.splitk, w.splitk_floats, s));
+  }
   TRY(launch_colsum(w.dvec, B, U, U, G(GVAE_P_DE2_B), 0, s));
-  TRY(linear_bwd_input(w.dvec, P.p[GVAE_P_DE2_W], w.dhe, B, U, H, 0, w.splitk, s));
-  TRY(launch_relu_mask(w.dhe, w.he, (int64_t)B * H, s));
-  TRY(linear_bwd_weight(w.dhe, w.z, Z, G(GVAE_P_DE1_W), B, H, Z, w.splitk, s));
-  TRY(launch_colsum(w.dhe, B, H, H, G(GVAE_P_DE1_B), 0, s));
-  TRY(linear_bwd_input(w.dhe, P.p[GVAE_P_DE1_W], w.dz, B, H, Z, 0, w.splitk, s));
-  // node head
-  TRY(linear_bwd_weight(w.dnode, w.hn, H, G(GVAE_P_DN2_W), B, N, H, w.splitk, s));
   TRY(launch_colsum(w.dnode, B, N, N, G(GVAE_P_DN2_B), 0, s));
-  TRY(linear_bwd_input(w.dnode, P.p[GVAE_P_DN2_W], w.dhn, B, N, H, 0, w.splitk, s));
+  TRY(launch_relu_mask(w.dhe, w.he, (int64_t)B * H, s));
   TRY(launch_relu_mask(w.dhn, w.hn, (int64_t)B * H, s));
-  TRY(linear_bwd_weight(w.dhn, w.z, Z, G(GVAE_P_DN1_W), B, H, Z, w.splitk, s));
+  {
+    GemmDesc l1[3] = {
+        desc_linear_bwd_weight(w.dhe, w.z, Z, G(GVAE_P_DE1_W), B, H, Z, nullptr),
+        desc_linear_bwd_weight(w.dhn, w.z, Z, G(GVAE_P_DN1_W), B, H, Z, nullptr),
+        desc_linear_bwd_input(w.dhe, P.p[GVAE_P_DE1_W], w.dz, B, H, Z, 0, nullptr)};
+    TRY(launch_gemm_group(l1, 3, w.splitk, w.splitk_floats, s));
+  }
+  TRY(launch_colsum(w.dhe, B, H, H, G(GVAE_P_DE1_B), 0, s));
   TRY(launch_colsum(w.dhn, B, H, H, G(GVAE_P_DN1_B), 0, s));
+  // dz = edge-head term + node-head term, in this order
   TRY(linear_bwd_input(w.dhn, P.p[GVAE_P_DN1_W], w.dz, B, H, Z, 1, w.splitk, s));
   // reparameterisation + KL
   TRY(launch_reparam_bwd(w.dz, w.mu, w.lvraw, d_eps, B, Z, c_kl, d_up, w.dmu, w.dlv, s));
-  TRY(linear_bwd_weight(w.dmu, w.gvec, H, G(GVAE_P_MU_W), B, Z, H, w.splitk, s));
+  {
+    GemmDesc hd[3] = {
+        desc_linear_bwd_weight(w.dmu, w.gvec, H, G(GVAE_P_MU_W), B, Z, H, nullptr),
+        desc_linear_bwd_weight(w.dlv, w.gvec, H, G(GVAE_P_LV_W), B, Z, H, nullptr),
+        desc_linear_bwd_input(w.dmu, P.p[GVAE_P_MU_W], w.dgvec, B, Z, H, 0, nullptr)};
+    TRY(launch_gemm_group(hd, 3, w.splitk, w.splitk_floats, s));
+  }
   TRY(launch_colsum(w.dmu, B, Z, Z, G(GVAE_P_MU_B), 0, s));
-  TRY(linear_bwd_weight(w.dlv, w.gvec, H, G(GVAE_P_LV_W), B, Z, H, w.splitk, s));
   TRY(launch_colsum(w.dlv, B, Z, Z, G(GVAE_P_LV_B), 0, s));
-  TRY(linear_bwd_input(w.dmu, P.p[GVAE_P_MU_W], w.dgvec, B, Z, H, 0, w.splitk, s));
   TRY(linear_bwd_input(w.dlv, P.p[GVAE_P_LV_W], w.dgvec, B, Z, H, 1, w.splitk, s));
   // encoder layer 2
   TRY(launch_pool_bwd(w.dgvec, d_n_x, d_R, B, N, H, w.dAct, s));
@@ -414,8 +451,12 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   TRY(launch_colsum(w.dbet_p, B, H, H, G(GVAE_P_BN2_B), 0, s));
   TRY(launch_colsum(w.dbias_p, B, H, H, G(GVAE_P_CONV2_B), 0, s));
   TRY(aggregate(w.Ahat, w.dY, w.dH0, B, N, H, s));  // Ahat is symmetric
-  TRY(linear_bwd_weight(w.dH0, w.H1, H, G(GVAE_P_CONV2_W), B * N, H, H, w.splitk, s));
-  TRY(linear_bwd_input(w.dH0, P.p[GVAE_P_CONV2_W], w.dAct, B * N, H, H, 0, w.splitk, s));
+  {
+    GemmDesc c2[2] = {
+        desc_linear_bwd_weight(w.dH0, w.H1, H, G(GVAE_P_CONV2_W), B * N, H, H, nullptr),
+        desc_linear_bwd_input(w.dH0, P.p[GVAE_P_CONV2_W], w.dAct, B * N, H, H, 0, nullptr)};
+    TRY(launch_gemm_group(c2, 2, w.splitk, w.splitk_floats, s));
+  }
   // encoder layer 1
   TRY(launch_bn_relu_bwd(w.dAct, w.Y1, P.p[GVAE_P_CONV1_B], w.H1, P.p[GVAE_P_BN1_W], w.mean1,
                          w.invstd1, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
