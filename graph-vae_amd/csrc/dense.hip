@@ -94,6 +94,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc &d, int bx, int by, int
       v += bv;
       if (d.accumulate) v += C[row * crs + col];
       if (d.relu) v = fmaxf(v, 0.0f);
+      if (d.relu_mask_act && !(d.relu_mask_act[row * crs + col] > 0.0f)) v = 0.0f;
     }
     C[row * crs + col] = v;
   }
@@ -123,6 +124,7 @@ __device__ __forceinline__ void splitk_reduce(const GemmDesc &d, int64_t e) {
   if (d.bias) v += d.bias[col];
   if (d.accumulate) v += d.C[row * d.c_rs + col];
   if (d.relu) v = fmaxf(v, 0.0f);
+  if (d.relu_mask_act && !(d.relu_mask_act[row * d.c_rs + col] > 0.0f)) v = 0.0f;
   d.C[row * d.c_rs + col] = v;
 }
 
@@ -446,6 +448,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ M
     for (int k = 0; k < 16; ++k) t += sh[k][cl];
     out[c] = accumulate ? out[c] + t : t;
   }
+}
+
+// several column sums in one launch (blockIdx.y = member), same arithmetic as colsum_kernel
+__global__ __launch_bounds__(256) void colsum_group_kernel(ColsumGroup g) {
+  __shared__ float sh[16][17];
+  const int k = blockIdx.y;
+  const float *__restrict__ M = g.M[k];
+  const int rows = g.rows[k], cols = g.cols[k];
+  const int64_t ld = g.ld[k];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  if ((int)blockIdx.x * 16 >= cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+      s0 += M[(int64_t)r * ld + c];
+      s1 += M[(int64_t)(r + 16) * ld + c];
+      s2 += M[(int64_t)(r + 32) * ld + c];
+      s3 += M[(int64_t)(r + 48) * ld + c];
+    }
+    for (; r < rows; r += 16) s0 += M[(int64_t)r * ld + c];
+  }
+  sh[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][cl];
+    g.out[k][c] = t;
+  }
+}
+
+int launch_colsum_group(const ColsumGroup &g, hipStream_t s) {
+  GVAE_REQUIRE(g.n >= 1 && g.n <= COLSUM_GROUP_MAX, GVAE_EINVAL, "colsum group: bad size %d", g.n);
+  int max_cols = 0;
+  for (int k = 0; k < g.n; ++k) max_cols = g.cols[k] > max_cols ? g.cols[k] : max_cols;
+  hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(max_cols, 16), g.n), dim3(256), 0, s, g);
+  return check_launch("colsum group");
 }
 
 int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,

@@ -18,6 +18,9 @@ struct GemmDesc {
   int batch = 1;
   int64_t a_bs = 0, b_bs = 0, c_bs = 0;
   int relu = 0, accumulate = 0;
+  // optional (M x N, same strides as C): the result is zeroed where act <= 0 (backward of a ReLU
+  // whose output is `act`), after bias / accumulation
+  const float *relu_mask_act = nullptr;
   // split-K (batch == 1 only): partial products go to `splitk_ws`
   // (splits * M * N floats) and are then summed in split order.
   int splits = 1;
@@ -56,6 +59,19 @@ int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, con
 // out[c] (+)= sum_r M[r*ld + c]   (rows summed in index order)
 int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
                   hipStream_t s);
+// out[k][c] = sum_r M[k][r*ld[k] + c] for up to COLSUM_GROUP_MAX matrices in one launch
+#define COLSUM_GROUP_MAX 4
+struct ColsumGroup {
+  const float *M[COLSUM_GROUP_MAX];
+  float *out[COLSUM_GROUP_MAX];
+  int rows[COLSUM_GROUP_MAX], cols[COLSUM_GROUP_MAX];
+  int64_t ld[COLSUM_GROUP_MAX];
+  int n = 0;
+  void add(const float *m, int r, int c, int64_t l, float *o) {
+    M[n] = m; rows[n] = r; cols[n] = c; ld[n] = l; out[n] = o; ++n;
+  }
+};
+int launch_colsum_group(const ColsumGroup &g, hipStream_t s);
 int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
                     float *gvec, hipStream_t s);
 int launch_pool_bwd(const float *dgvec, const int32_t *n_x, const int32_t *R, int B, int N, int H,

@@ -414,12 +414,18 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
         desc_linear_bwd_input(w.dvec, P.p[GVAE_P_DE2_W], w.dhe, B, U, H, 0, nullptr),
         desc_linear_bwd_weight(w.dnode, w.hn, H, G(GVAE_P_DN2_W), B, N, H, nullptr),
         desc_linear_bwd_input(w.dnode, P.p[GVAE_P_DN2_W], w.dhn, B, N, H, 0, nullptr)};
+    l2[1].relu_mask_act = w.he;   // backward of the hidden ReLUs, in the contraction's epilogue
+    l2[3].relu_mask_act = w.hn;
     TRY(launch_gemm_group(l2, 4, w.splitk, w.splitk_floats, s));
   }
-  TRY(launch_colsum(w.dvec, B, U, U, G(GVAE_P_DE2_B), 0, s));
-  TRY(launch_colsum(w.dnode, B, N, N, G(GVAE_P_DN2_B), 0, s));
-  TRY(launch_relu_mask(w.dhe, w.he, (int64_t)B * H, s));
-  TRY(launch_relu_mask(w.dhn, w.hn, (int64_t)B * H, s));
+  {
+    ColsumGroup cs;   // the four bias gradients of the two heads
+    cs.add(w.dvec, B, U, U, G(GVAE_P_DE2_B));
+    cs.add(w.dnode, B, N, N, G(GVAE_P_DN2_B));
+    cs.add(w.dhe, B, H, H, G(GVAE_P_DE1_B));
+    cs.add(w.dhn, B, H, H, G(GVAE_P_DN1_B));
+    TRY(launch_colsum_group(cs, s));
+  }
   {
     GemmDesc l1[3] = {
         desc_linear_bwd_weight(w.dhe, w.z, Z, G(GVAE_P_DE1_W), B, H, Z, nullptr),
@@ -427,8 +433,6 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
         desc_linear_bwd_input(w.dhe, P.p[GVAE_P_DE1_W], w.dz, B, H, Z, 0, nullptr)};
     TRY(launch_gemm_group(l1, 3, w.splitk, w.splitk_floats, s));
   }
-  TRY(launch_colsum(w.dhe, B, H, H, G(GVAE_P_DE1_B), 0, s));
-  TRY(launch_colsum(w.dhn, B, H, H, G(GVAE_P_DN1_B), 0, s));
   // dz = edge-head term + node-head term, in this order
   TRY(linear_bwd_input(w.dhn, P.p[GVAE_P_DN1_W], w.dz, B, H, Z, 1, w.splitk, s));
   // reparameterisation + KL
@@ -440,16 +444,24 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
         desc_linear_bwd_input(w.dmu, P.p[GVAE_P_MU_W], w.dgvec, B, Z, H, 0, nullptr)};
     TRY(launch_gemm_group(hd, 3, w.splitk, w.splitk_floats, s));
   }
-  TRY(launch_colsum(w.dmu, B, Z, Z, G(GVAE_P_MU_B), 0, s));
-  TRY(launch_colsum(w.dlv, B, Z, Z, G(GVAE_P_LV_B), 0, s));
+  {
+    ColsumGroup cs;
+    cs.add(w.dmu, B, Z, Z, G(GVAE_P_MU_B));
+    cs.add(w.dlv, B, Z, Z, G(GVAE_P_LV_B));
+    TRY(launch_colsum_group(cs, s));
+  }
   TRY(linear_bwd_input(w.dlv, P.p[GVAE_P_LV_W], w.dgvec, B, Z, H, 1, w.splitk, s));
   // encoder layer 2
   TRY(launch_pool_bwd(w.dgvec, d_n_x, d_R, B, N, H, w.dAct, s));
   TRY(launch_bn_relu_bwd(w.dAct, w.Y2, P.p[GVAE_P_CONV2_B], w.H2, P.p[GVAE_P_BN2_W], w.mean2,
                          w.invstd2, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
-  TRY(launch_colsum(w.dgam_p, B, H, H, G(GVAE_P_BN2_W), 0, s));
-  TRY(launch_colsum(w.dbet_p, B, H, H, G(GVAE_P_BN2_B), 0, s));
-  TRY(launch_colsum(w.dbias_p, B, H, H, G(GVAE_P_CONV2_B), 0, s));
+  {
+    ColsumGroup cs;
+    cs.add(w.dgam_p, B, H, H, G(GVAE_P_BN2_W));
+    cs.add(w.dbet_p, B, H, H, G(GVAE_P_BN2_B));
+    cs.add(w.dbias_p, B, H, H, G(GVAE_P_CONV2_B));
+    TRY(launch_colsum_group(cs, s));
+  }
   TRY(aggregate(w.Ahat, w.dY, w.dH0, B, N, H, s));  // Ahat is symmetric
   {
     GemmDesc c2[2] = {
@@ -460,9 +472,13 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   // encoder layer 1
   TRY(launch_bn_relu_bwd(w.dAct, w.Y1, P.p[GVAE_P_CONV1_B], w.H1, P.p[GVAE_P_BN1_W], w.mean1,
                          w.invstd1, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
-  TRY(launch_colsum(w.dgam_p, B, H, H, G(GVAE_P_BN1_W), 0, s));
-  TRY(launch_colsum(w.dbet_p, B, H, H, G(GVAE_P_BN1_B), 0, s));
-  TRY(launch_colsum(w.dbias_p, B, H, H, G(GVAE_P_CONV1_B), 0, s));
+  {
+    ColsumGroup cs;
+    cs.add(w.dgam_p, B, H, H, G(GVAE_P_BN1_W));
+    cs.add(w.dbet_p, B, H, H, G(GVAE_P_BN1_B));
+    cs.add(w.dbias_p, B, H, H, G(GVAE_P_CONV1_B));
+    TRY(launch_colsum_group(cs, s));
+  }
   TRY(aggregate(w.Ahat, w.dY, w.dH0, B, N, H, s));
   TRY(linear_bwd_weight(w.dH0, d_x, F, G(GVAE_P_CONV1_W), B * N, H, F, w.splitk, s));
   return check_launch("step_backward");
