@@ -162,7 +162,9 @@ class StepEngine:
         if self._S is None or self._S.numel() < largest:
             self._S = None  # release before growing
             self._S = torch.empty(max(largest, 4), dtype=torch.float32, device=self.device)
-        self._S_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        # staged through pinned memory: a pageable upload would make the host wait for the
+        # device to drain on every batch with a new size pattern
+        self._S_off = torch.tensor(offs, dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
         self._S_chunks = (c_int32 * len(begin))(*begin)
         self._S_key = key
 
