@@ -301,3 +301,30 @@ def test_stream_rejects_graph_larger_than_launch(hip):
     X = hip.x0_uniform(Rh, 9, dev)
     done = hip.mpm_stream(S, S_off, R, 8, X, 5, 1e-4, True, layout=hip.S_PADDED)   # r_max 8 < 9
     assert (done < 0).all()
+
+
+def test_dense_layout_wide_workgroups(hip):
+    """Dense (unpadded) S with node counts of every residue mod 4 in a launch that uses the
+    1024-thread work-groups (r_max >= 48): same X and iteration counts as the padded layout."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    Rh = [49, 50, 51, 52, 7, 2]
+    N = max(Rh)
+    As, Ps = [], []
+    for R in Rh:
+        up = np.triu((rng.random((R, R)) < 0.3).astype(np.float32), 1)
+        As.append(up + up.T + np.eye(R, dtype=np.float32))
+        lg = np.triu(rng.normal(0, 1.0, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    A = torch.from_numpy(_pack(As, N)).to(dev)
+    P = torch.from_numpy(_pack(Ps, N)).to(dev)
+    R = torch.tensor(Rh, dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    Sd, offd = hip.edge_sim(A, P, NS, R, Rh, hip.S_DENSE)
+    Sp, offp = hip.edge_sim(A, P, NS, R, Rh, hip.S_PADDED)
+    Xd, Xp = hip.x0_uniform(Rh, N, dev), hip.x0_uniform(Rh, N, dev)
+    dd = hip.mpm_stream(Sd, offd, R, N, Xd, 6, 1e-4, True, layout=hip.S_DENSE)
+    dp = hip.mpm_stream(Sp, offp, R, N, Xp, 6, 1e-4, True, layout=hip.S_PADDED)
+    assert torch.equal(dd, dp) and torch.equal(Xd, Xp)
+    Xo, done = ora.mpm_sfree(As[0], Ps[0], None, 6, 1e-4, True)
+    assert int(dp[0]) == done and np.array_equal(Xp[0, :49, :49].cpu().numpy(), Xo)
