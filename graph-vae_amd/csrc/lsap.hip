@@ -24,8 +24,15 @@ namespace gvae {
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  int lo2, hi2;
+  if constexpr (ROW_MASK == 0xf) {
+    // every lane is written: no previous value to keep, which spares the copy of it
+    lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  } else {
+    lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  }
   return __hiloint2double(hi2, lo2);
 }
 __device__ __forceinline__ double read_lane_f64(double v, int lane) {
@@ -39,25 +46,34 @@ __device__ __forceinline__ double min1_f64(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// LANES = 16, 32 or 64: how many leading lanes can hold data (the others hold the identity);
+// the row-combining steps a narrower problem does not need are left out.
+template <int LANES = 64>
 __device__ __forceinline__ double wave_min_f64(double v) {
   v = min1_f64(v, dpp_f64<0xB1>(v));        // quad_perm [1,0,3,2]
   v = min1_f64(v, dpp_f64<0x4E>(v));        // quad_perm [2,3,0,1]
   v = min1_f64(v, dpp_f64<0x141>(v));       // row_half_mirror
   v = min1_f64(v, dpp_f64<0x140>(v));       // row_mirror: every lane of a row holds the row's minimum
+  if constexpr (LANES == 16) return read_lane_f64(v, 15);
   v = min1_f64(v, dpp_f64<0x142, 0xa>(v));  // row_bcast15: rows 1 and 3 take in rows 0 and 2
+  if constexpr (LANES == 32) return read_lane_f64(v, 31);
   v = min1_f64(v, dpp_f64<0x143, 0xc>(v));  // row_bcast31: rows 2 and 3 take in row 1
   return read_lane_f64(v, 63);
 }
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+  if constexpr (ROW_MASK == 0xf) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
+  else return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
+template <int LANES = 64>
 __device__ __forceinline__ int wave_max_i32(int v) {
   v = max(v, dpp_i32<0xB1>(v));
   v = max(v, dpp_i32<0x4E>(v));
   v = max(v, dpp_i32<0x141>(v));
   v = max(v, dpp_i32<0x140>(v));
+  if constexpr (LANES == 16) return __builtin_amdgcn_readlane(v, 15);
   v = max(v, dpp_i32<0x142, 0xa>(v));
+  if constexpr (LANES == 32) return __builtin_amdgcn_readlane(v, 31);
   v = max(v, dpp_i32<0x143, 0xc>(v));
   return __builtin_amdgcn_readlane(v, 63);
 }
@@ -92,7 +108,7 @@ __device__ __forceinline__ double pick_f64(const double (&a)[NCH], int idx) {
 // The sequential rule "among the columns at the minimum distance, the last unassigned one in
 // list order, else the first one in list order" becomes one integer maximum over the keys
 //   unassigned: 0x10000 + pos      assigned: 0xFFFF - pos      (list positions are unique)
-template <int NCH>
+template <int NCH, int LANES = 64>
 __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, int (&col4row)[NCH]) {
   double u[NCH], v[NCH], spc[NCH];
   int path[NCH], row4col[NCH], pos[NCH];
@@ -128,7 +144,7 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
           lowest = spc[c] < lowest ? spc[c] : lowest;
         }
       }
-      lowest = wave_min_f64(lowest);
+      lowest = wave_min_f64<LANES>(lowest);
       if (lowest == INFINITY) return 1;      // infeasible
       // columns at the minimum distance: usually exactly one, which the ballot names directly;
       // only a tie needs the second wave-wide reduction over the selection keys
@@ -153,7 +169,7 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
             key = max(key, k);
           }
         }
-        const int best = wave_max_i32(key);
+        const int best = wave_max_i32<LANES>(key);
         const int L = __ffsll((long long)__ballot(key == best)) - 1;
         j = (best & 1) * 64 + L;
       }
@@ -233,7 +249,9 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ X, i
   int fail;
   if (n <= 64) {
     int col4row[1];
-    fail = lsap_solve<1>(cost, n, lane, col4row);
+    if (n <= 16) fail = lsap_solve<1, 16>(cost, n, lane, col4row);
+    else if (n <= 32) fail = lsap_solve<1, 32>(cost, n, lane, col4row);
+    else fail = lsap_solve<1>(cost, n, lane, col4row);
     if (!fail && lane < n) pg[col4row[0]] = lane;            // perm[col4row[i]] = i
   } else {
     int col4row[2];
