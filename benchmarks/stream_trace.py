@@ -1,7 +1,7 @@
 """Timeline of the streamed MPM from a trace build of the library (-DGVAE_STREAM_TRACE):
 how many work-groups stream at a time, and where a graph's iteration spends its time once
 the device is no longer full.
-usage: GVAE_HIP_LIB=<trace build> python benchmarks/stream_trace.py [N] [B] [iters] [early_stop] [bench-batch 0|1]"""
+usage: GVAE_HIP_LIB=<trace build> python benchmarks/stream_trace.py [N] [B] [iters] [early_stop] [enzymes]"""
 import ctypes
 import sys
 from pathlib import Path
@@ -17,13 +17,24 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 es = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+ragged = len(sys.argv) > 5 and sys.argv[5] == "enzymes"
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
-up = torch.triu((torch.rand(B, N, N, generator=gen) < 0.5).float(), 1)
-A = (up + up.transpose(1, 2) + torch.eye(N)).to(dev)
+if ragged:          # ENZYMES-shaped sizes and sparsity, padded to N
+    from graphvae.data import synthetic_adjacencies
+    adjs = synthetic_adjacencies("enzymes", B, N, seed=1000)
+    Rh = [a.shape[0] for a in adjs]
+    A = torch.zeros(B, N, N)
+    for k, a in enumerate(adjs):
+        r = a.shape[0]
+        A[k, :r, :r] = torch.from_numpy(a) + torch.eye(r)
+    A = A.to(dev)
+else:
+    up = torch.triu((torch.rand(B, N, N, generator=gen) < 0.5).float(), 1)
+    A = (up + up.transpose(1, 2) + torch.eye(N)).to(dev)
+    Rh = [N] * B
 lg = torch.triu(torch.randn(B, N, N, generator=gen) * 0.3, 1)
 P = torch.sigmoid(lg + lg.transpose(1, 2)).to(dev).contiguous()
-Rh = [N] * B
 R = torch.tensor(Rh, dtype=torch.int32, device=dev)
 NS = _hip.node_sim(A, P, R)
 S, S_off = _hip.edge_sim(A, P, NS, R, Rh, 1)
@@ -40,7 +51,8 @@ for rep in range(2):                       # the second run is the one analysed
     done = _hip.mpm_stream(S, S_off, R, N, X, iters, 1e-4, es, ws=ws, layout=1)
     torch.cuda.synchronize()
 n = L.gvae_debug_trace_count()
-print(f"{n} item records, {int(done.sum())} graph-iterations")
+print(f"{n} item records, {int(done.sum())} graph-iterations; sizes max {max(Rh)} mean {sum(Rh)/len(Rh):.1f}; "
+      f"algorithmic bytes {sum(int(d) * (4 * r ** 4 + 12 * r * r) for d, r in zip(done.tolist(), Rh)) / 1e9:.2f} GB")
 t = buf[: 8 * n].cpu().numpy().reshape(n, 8).astype(np.int64)
 item = t[:, 0] & 0xFFFFFFFF
 g = item >> 16

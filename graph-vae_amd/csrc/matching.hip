@@ -449,7 +449,7 @@ __host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive,
   long long t = (slab + (2LL << 20) - 1) >> 21;
   t = t < 1 ? 1 : t;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R * t;
-  if (in_flight < low) t *= low / in_flight;
+  if (in_flight < low) t *= (low + in_flight - 1) / in_flight;
   int nb = t > MPM_MAX_COL_BLOCKS ? MPM_MAX_COL_BLOCKS : (int)t;
   nb = nb > R ? R : nb;
   for (;;) {
@@ -1259,7 +1259,10 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                    hipMemsetAsync(q.slots, 0, 8 * (size_t)n_items, s) == hipSuccess,
                GVAE_ELAUNCH, "mpm_stream: memset failed");
   // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
-  // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win
+  // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win.
+  // (Running a ragged batch as two launches, small graphs with 256 threads and a small LDS
+  // footprint, then the large ones, was measured too: 4.84 against 4.56 ms on ENZYMES-shaped
+  // batches, whose time is set by the chains of the few graphs that need all their iterations.)
   int nt = r_max >= 48 ? 1024 : 256;
   // measured on 256 graphs of 32 nodes with early stop: 2.77 ms at (1024, 4096) against 2.84 at
   // (256, 2048); grouping rows at all: 16-node graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512
