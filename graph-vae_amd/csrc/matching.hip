@@ -231,6 +231,9 @@ __device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab, int R
 #ifndef GVAE_STREAM_DEPTH
 #define GVAE_STREAM_DEPTH 4
 #endif
+#ifndef GVAE_POLL_SLEEP
+#define GVAE_POLL_SLEEP 16   // units of 64 cycles between two polls of a consumer's queue slot
+#endif
 #ifndef GVAE_STREAM_WAVES
 #define GVAE_STREAM_WAVES 5
 #endif
@@ -582,7 +585,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_store(Q_ERROR(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(GVAE_POLL_SLEEP);
       }
       s_item = got ? (int)item : -2;
     }
@@ -739,7 +742,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
             unsigned long long *sl = &q.slots[t % q.cap];
             // the ticket one lap earlier has been drawn by now (at most `cap` items are ever
             // undrawn), so its consumer is polling this slot and frees it promptly
+            // (on the first lap the slot is still as the host zeroed it: nothing to wait for)
             for (unsigned spins = 0;
+                 t >= q.cap &&
                  __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull; ++spins) {
               if (spins > MPM_SPIN_LIMIT) {
                 __hip_atomic_store(Q_ERROR(q), 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
