@@ -111,13 +111,14 @@ __device__ __forceinline__ double pick_f64(const double (&a)[NCH], int idx) {
 template <int NCH, int LANES = 64>
 __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, int (&col4row)[NCH]) {
   double u[NCH], v[NCH], spc[NCH];
-  int path[NCH], row4col[NCH], pos[NCH];
-  bool SR[NCH], SC[NCH];
+  int path[NCH], row4col[NCH], pos[NCH], ccol[NCH];
+  // scanned rows / columns of the current augmentation as wave-uniform bit masks
+  unsigned long long sr[NCH], sc[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     u[c] = 0.0; v[c] = 0.0; spc[c] = INFINITY;
     path[c] = -1; row4col[c] = -1; col4row[c] = -1; pos[c] = -1;
-    SR[c] = false; SC[c] = false;
+    ccol[c] = min(c * 64 + lane, n - 1);     // lanes past the matrix re-read its last column
   }
   for (int cur = 0; cur < n; ++cur) {
     double minVal = 0.0;
@@ -126,23 +127,26 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 64 + lane;
       pos[c] = col < n ? n - 1 - col : -1;   // the list starts as n-1, n-2, ..., 0
-      SR[c] = false; SC[c] = false;
+      sr[c] = 0ull; sc[c] = 0ull;
       spc[c] = INFINITY;
     }
+    // The inner loop is a single dependent chain executed by one wavefront: it is written
+    // without per-lane control flow (selects instead of branches, the cost row read by every
+    // lane), which is what its latency is made of.
     while (sink == -1) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (c * 64 + lane == i) SR[c] = true;
+      if (NCH == 1 || i < 64) sr[0] |= 1ull << (i & 63);
+      else sr[NCH - 1] |= 1ull << (i & 63);
       const double ui = pick_f64<NCH>(u, i);
       const float *crow = cost + i * n;
       double lowest = INFINITY;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (pos[c] >= 0) {
-          const double r = minVal + (double)(-crow[c * 64 + lane]) - ui - v[c];
-          if (r < spc[c]) { path[c] = i; spc[c] = r; }
-          lowest = spc[c] < lowest ? spc[c] : lowest;
-        }
+        const bool act = pos[c] >= 0;
+        const double r = minVal + (double)(-crow[ccol[c]]) - ui - v[c];
+        const bool upd = act && r < spc[c];
+        spc[c] = upd ? r : spc[c];
+        path[c] = upd ? i : path[c];
+        lowest = min1_f64(act ? spc[c] : INFINITY, lowest);
       }
       lowest = wave_min_f64<LANES>(lowest);
       if (lowest == INFINITY) return 1;      // infeasible
@@ -164,10 +168,8 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
         int key = -1;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-          if (at_min[c]) {
-            const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
-            key = max(key, k);
-          }
+          const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
+          key = max(key, at_min[c] ? k : -1);
         }
         const int best = wave_max_i32<LANES>(key);
         const int L = __ffsll((long long)__ballot(key == best)) - 1;
@@ -180,9 +182,11 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
       // remove j from the list: the list's last entry moves into j's place
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (pos[c] == num_remaining - 1) pos[c] = pj;
-        if (c * 64 + lane == j) { pos[c] = -1; SC[c] = true; }
+        pos[c] = pos[c] == num_remaining - 1 ? pj : pos[c];
+        pos[c] = c * 64 + lane == j ? -1 : pos[c];
       }
+      if (NCH == 1 || j < 64) sc[0] |= 1ull << (j & 63);
+      else sc[NCH - 1] |= 1ull << (j & 63);
       --num_remaining;
     }
     // dual updates
@@ -196,9 +200,10 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
         const double s1 = __shfl(spc[1], cr & 63, 64);
         if (cr >= 64) s_cr = s1;
       }
+      const bool in_sr = (sr[c] >> lane) & 1ull, in_sc = (sc[c] >> lane) & 1ull;
       if (row == cur) u[c] += minVal;
-      else if (SR[c]) u[c] += minVal - s_cr;
-      if (SC[c]) v[c] -= minVal - spc[c];
+      else if (in_sr) u[c] += minVal - s_cr;
+      if (in_sc) v[c] -= minVal - spc[c];
     }
     // augment along the path (wave-uniform walk)
     int j = sink;
