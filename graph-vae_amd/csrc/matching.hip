@@ -370,22 +370,25 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
 
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
 __device__ __forceinline__ float norm_chain(const float *x, int n, int lane, float acc) {
-  // the fused chain itself is serial; keep the next 8 operands in flight while it runs
+  // the fused chain itself is serial (one dependent fma per element of the lane); the next
+  // 16 operands are read from LDS while the current 16 are consumed, which covers the LDS
+  // latency with 16 dependent fma (8 would not)
+  constexpr int NB = 16;
   int d = 0;
-  if (n >= 64) {
-    float v[8], w[8];
+  if (n >= 8 * NB) {
+    float v[NB], w[NB];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = x[8 * t + lane];
-    for (d = 64; d + 64 <= n; d += 64) {
+    for (int t = 0; t < NB; ++t) v[t] = x[8 * t + lane];
+    for (d = 8 * NB; d + 8 * NB <= n; d += 8 * NB) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) w[t] = x[d + 8 * t + lane];
+      for (int t = 0; t < NB; ++t) w[t] = x[d + 8 * t + lane];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc = __fmaf_rn(v[t], v[t], acc);
+      for (int t = 0; t < NB; ++t) acc = __fmaf_rn(v[t], v[t], acc);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = w[t];
+      for (int t = 0; t < NB; ++t) v[t] = w[t];
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc = __fmaf_rn(v[t], v[t], acc);
+    for (int t = 0; t < NB; ++t) acc = __fmaf_rn(v[t], v[t], acc);
   }
   for (; d < n; d += 8) {
     const float v = x[d + lane];
