@@ -622,6 +622,8 @@ int launch_prob(const float *vec, const float *node, int B, int N, float *P, hip
 //   edge BCE-with-logits (pos_weight) over the R(R-1)/2 permuted pairs, mean
 //   node BCE-with-logits over N entries, targets 1 for k < R, weight clamp((N-R)/(R+1e-8),1,5)
 //   KL = -0.5 * mean_Z(1 + lv - mu^2 - exp(lv))
+// mask_dummy != 0 is the older loss (model.py:403-408,425-427): node logits of padded
+// entries are read as the constant -10, in the loss and hence (zero) in its gradient.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float bce_logits(float x, float y, float pw) {
   const float lw = 1.0f + (pw - 1.0f) * y;
@@ -649,7 +651,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
     const float *__restrict__ vec, const float *__restrict__ node, const float *__restrict__ adj,
     const float *__restrict__ mu, const float *__restrict__ lvraw, const int64_t *__restrict__ perm,
     const int32_t *__restrict__ Rarr, int N, int Z, const float *__restrict__ pos_weight,
-    float *__restrict__ rec_i, float *__restrict__ kl_i, float *__restrict__ maxlogit_i) {
+    int mask_dummy, float *__restrict__ rec_i, float *__restrict__ kl_i,
+    float *__restrict__ maxlogit_i) {
   __shared__ float sh[4];
   const int g = blockIdx.x, tid = threadIdx.x;
   const int R = Rarr[g], U = N * (N - 1) / 2;
@@ -675,7 +678,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
   // node term
   const float pwn = fminf(fmaxf((float)(N - R) / ((float)R + 1e-8f), 1.0f), 5.0f);
   s = 0.0f;
-  for (int k = tid; k < N; k += 256) s += bce_logits(ng[k], k < R ? 1.0f : 0.0f, pwn);
+  for (int k = tid; k < N; k += 256)
+    s += bce_logits(mask_dummy && k >= R ? -10.0f : ng[k], k < R ? 1.0f : 0.0f, pwn);
   const float nodel = block_sum_256(s, sh) / (float)N;
   // KL
   s = 0.0f;
@@ -728,10 +732,10 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restric
 
 int launch_loss_fwd(const float *vec, const float *node, const float *adj, const float *mu,
                     const float *lvraw, const int64_t *perm, const int32_t *R, int B, int N, int Z,
-                    const float *pos_weight, float *rec_i, float *kl_i, float *maxlogit_i,
-                    float *out4, hipStream_t s) {
+                    const float *pos_weight, int mask_dummy, float *rec_i, float *kl_i,
+                    float *maxlogit_i, float *out4, hipStream_t s) {
   hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, s, vec, node, adj, mu, lvraw, perm, R, N,
-                     Z, pos_weight, rec_i, kl_i, maxlogit_i);
+                     Z, pos_weight, mask_dummy, rec_i, kl_i, maxlogit_i);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, rec_i, kl_i, maxlogit_i, lvraw, B,
                      Z, out4);
   return check_launch("loss_fwd");
@@ -743,8 +747,8 @@ int launch_loss_fwd(const float *vec, const float *node, const float *adj, const
 // with cr = c_rec * d_up[0] / B.
 __global__ void loss_bwd_kernel(const float *__restrict__ vec, const float *__restrict__ node,
                                 const float *__restrict__ adj, const int32_t *__restrict__ Rarr,
-                                int N, const float *__restrict__ pos_weight, float cr,
-                                const float *__restrict__ d_up, float *__restrict__ dvec,
+                                int N, const float *__restrict__ pos_weight, int mask_dummy,
+                                float cr, const float *__restrict__ d_up, float *__restrict__ dvec,
                                 float *__restrict__ dnode) {
   const int g = blockIdx.y;
   const int R = Rarr[g], U = N * (N - 1) / 2;
@@ -769,16 +773,17 @@ __global__ void loss_bwd_kernel(const float *__restrict__ vec, const float *__re
       const float x = node[(int64_t)g * N + a], y = a < R ? 1.0f : 0.0f;
       const float lw = 1.0f + (pwn - 1.0f) * y;
       const float sg = 1.0f / (1.0f + expf(-x));
-      dnode[(int64_t)g * N + a] = cr / (float)N * ((1.0f - y) - lw * (1.0f - sg));
+      dnode[(int64_t)g * N + a] =
+          mask_dummy && a >= R ? 0.0f : cr / (float)N * ((1.0f - y) - lw * (1.0f - sg));
     }
   }
 }
 
 int launch_loss_bwd(const float *vec, const float *node, const float *adj, const int32_t *R, int B,
-                    int N, const float *pos_weight, float c_rec, const float *d_up, float *dvec,
-                    float *dnode, hipStream_t s) {
+                    int N, const float *pos_weight, int mask_dummy, float c_rec, const float *d_up,
+                    float *dvec, float *dnode, hipStream_t s) {
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, vec,
-                     node, adj, R, N, pos_weight, c_rec / (float)B, d_up, dvec, dnode);
+                     node, adj, R, N, pos_weight, mask_dummy, c_rec / (float)B, d_up, dvec, dnode);
   return check_launch("loss_bwd");
 }
 

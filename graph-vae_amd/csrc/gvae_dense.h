@@ -86,10 +86,10 @@ int launch_relu_mask(float *dX, const float *act, int64_t n, hipStream_t s);
 int launch_prob(const float *vec, const float *node, int B, int N, float *P, hipStream_t s);
 int launch_loss_fwd(const float *vec, const float *node, const float *adj, const float *mu,
                     const float *lvraw, const int64_t *perm, const int32_t *R, int B, int N, int Z,
-                    const float *pos_weight, float *rec_i, float *kl_i, float *maxlogit_i,
-                    float *out4, hipStream_t s);
+                    const float *pos_weight, int mask_dummy, float *rec_i, float *kl_i,
+                    float *maxlogit_i, float *out4, hipStream_t s);
 int launch_loss_bwd(const float *vec, const float *node, const float *adj, const int32_t *R, int B,
-                    int N, const float *pos_weight, float c_rec, const float *d_up, float *dvec,
-                    float *dnode, hipStream_t s);
+                    int N, const float *pos_weight, int mask_dummy, float c_rec, const float *d_up,
+                    float *dvec, float *dnode, hipStream_t s);
 
 }  // namespace gvae

@@ -290,8 +290,8 @@ int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs) {
 
 int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
-                      int r_max, const float *d_eps, const float *d_pos_weight, int train,
-                      int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                      int r_max, const float *d_eps, const float *d_pos_weight, int loss_variant,
+                      int train, int matching, int mpm_iters, float tol, int early_stop, float *d_S,
                       const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
                       void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
                       void *stream) {
@@ -302,6 +302,8 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
                "step_forward: bad sizes (n_graphs=%d r_max=%d N=%d)", n_graphs, r_max, d->N);
   GVAE_REQUIRE(matching >= GVAE_MATCH_NONE && matching <= GVAE_MATCH_FUSED, GVAE_EINVAL,
                "step_forward: unknown matching mode %d", matching);
+  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
+               GVAE_EINVAL, "step_forward: unknown loss variant %d", loss_variant);
   GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
                "step_forward: streaming matching needs the S buffer and its offsets");
   GVAE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || h_chunk_begin), GVAE_EINVAL,
@@ -385,19 +387,21 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
   }
   // losses (model.py:325-373)
   TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,
-                      w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
+                      loss_variant == GVAE_LOSS_DUMMY_MASKED, w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
   return check_launch("step_forward");
 }
 
 int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d_x,
                        const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
-                       const float *d_eps, const float *d_pos_weight, float c_rec, float c_kl,
-                       const float *d_up, void *d_ws, float *d_grads, void *stream) {
+                       const float *d_eps, const float *d_pos_weight, int loss_variant, float c_rec,
+                       float c_kl, const float *d_up, void *d_ws, float *d_grads, void *stream) {
   GVAE_REQUIRE(d && d_params && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight && d_ws &&
                    d_grads,
                GVAE_EINVAL, "step_backward: null pointer");
   GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535, GVAE_EINVAL, "step_backward: bad n_graphs=%d",
                n_graphs);
+  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
+               GVAE_EINVAL, "step_backward: unknown loss variant %d", loss_variant);
   hipStream_t s = (hipStream_t)stream;
   const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
   const Workspace w = carve(d, B, (char *)d_ws);
@@ -406,7 +410,8 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   param_layout(d, off, nullptr);
   auto G = [&](int i) { return d_grads + off[i]; };
 
-  TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight, c_rec, d_up, w.dvec, w.dnode, s));
+  TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight,
+                      loss_variant == GVAE_LOSS_DUMMY_MASKED, c_rec, d_up, w.dvec, w.dnode, s));
   // edge and node heads, layer by layer: the four contractions of a layer are independent
   {
     GemmDesc l2[4] = {

@@ -16,6 +16,7 @@ from .data import DenseGraphBatch
 P_COUNT = 20
 MATCH_NONE, MATCH_STREAM, MATCH_FUSED = 0, 1, 2
 _MATCH = {"none": MATCH_NONE, "stream": MATCH_STREAM, "fused": MATCH_FUSED}
+LOSS_CURRENT, LOSS_DUMMY_MASKED = 0, 1   # GVAE_LOSS_* of the library
 
 # parameter tensors in flat-buffer order (reference module named_parameters() order)
 PARAM_NAMES = [
@@ -45,11 +46,11 @@ def _bind():
     L.gvae_step_ws_bytes.restype = c_int64
     L.gvae_step_forward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_float, c_int, c_void_p, c_void_p, POINTER(c_int32), c_int,
+                                    c_int, c_float, c_int, c_void_p, c_void_p, POINTER(c_int32), c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.gvae_step_backward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
-                                     c_void_p, c_void_p]
+                                     c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]
     L.gvae_step_read_debug.argtypes = [POINTER(Dims), c_int, c_void_p, c_int, POINTER(c_void_p),
                                        POINTER(c_int64)]
     L.gvae_adam_ws_bytes.restype = c_int64
@@ -182,9 +183,14 @@ class StepEngine:
 
     # ------------------------------------------------------------------ step pieces
     def forward(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,
-                eps: torch.Tensor, pos_weight: torch.Tensor, train: bool) -> torch.Tensor:
+                eps: torch.Tensor, pos_weight: torch.Tensor, train: bool,
+                loss_variant: int = LOSS_CURRENT) -> torch.Tensor:
         """Runs the forward; returns the device tensor [rec, kl, max_logit, logvar_max]
-        (a view of engine memory, overwritten by the next forward)."""
+        (a view of engine memory, overwritten by the next forward).  `loss_variant`:
+        LOSS_CURRENT (reference model.py:281-373) or LOSS_DUMMY_MASKED (`forward_old`,
+        model.py:378-440); the backward of this batch uses the same variant."""
+        if loss_variant not in (LOSS_CURRENT, LOSS_DUMMY_MASKED):
+            raise ValueError(f"unknown loss variant {loss_variant}")
         self._check_batch(batch)
         B = batch.num_graphs
         self._ensure(B)
@@ -202,12 +208,12 @@ class StepEngine:
         _hip._check(self.L.gvae_step_forward(
             ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
             batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B, r_max,
-            eps.data_ptr(), pos_weight.data_ptr(), int(train), mode, self.mpm_iters, self.tol,
+            eps.data_ptr(), pos_weight.data_ptr(), int(loss_variant), int(train), mode, self.mpm_iters, self.tol,
             int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
             self.out4.data_ptr(),
             self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
         self.generation += 1
-        self._fwd_batch = (batch, eps)
+        self._fwd_batch = (batch, eps, int(loss_variant))
         self.last_mode = mode
         return self.out4
 
@@ -217,7 +223,7 @@ class StepEngine:
         batch of the most recent forward."""
         if self._fwd_batch is None:
             raise _hip.GvaeHipError("backward called before forward")
-        batch, eps = self._fwd_batch
+        batch, eps, loss_variant = self._fwd_batch
         _hip._dev(grads, torch.float32)
         up = None
         if d_up is not None:
@@ -226,7 +232,7 @@ class StepEngine:
         _hip._check(self.L.gvae_step_backward(
             ctypes.byref(self.dims), params.data_ptr(), batch.x.data_ptr(), batch.adj_dense.data_ptr(),
             batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), batch.num_graphs, eps.data_ptr(),
-            pos_weight.data_ptr(), float(c_rec), float(c_kl), up, self._ws.data_ptr(),
+            pos_weight.data_ptr(), loss_variant, float(c_rec), float(c_kl), up, self._ws.data_ptr(),
             grads.data_ptr(), _hip._stream()))
 
     def adam_step(self, params, grads, m, v, step: int, lr: float, betas=(0.9, 0.999),

@@ -1,1 +1,1 @@
-from .metrics import clustering_coef, degree_histogram  # noqa: F401
+from .metrics import aspl, batch_stat, clustering_coef, degree_histogram, degree_l1  # noqa: F401

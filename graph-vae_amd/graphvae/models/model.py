@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from .. import _hip
 from ..data import DenseGraphBatch, as_dense_batch
-from ..engine import PARAM_NAMES, StepEngine, param_layout
+from ..engine import LOSS_CURRENT, LOSS_DUMMY_MASKED, PARAM_NAMES, StepEngine, param_layout
 
 
 def vec_to_adj(vec: torch.Tensor, N: int, *, diag: bool = False) -> torch.Tensor:
@@ -82,10 +82,10 @@ class _StepFunction(torch.autograd.Function):
     """Autograd bridge: forward and backward both run inside libgvae_hip.so."""
 
     @staticmethod
-    def forward(ctx, model, batch, eps, *params):
+    def forward(ctx, model, batch, eps, loss_variant, *params):
         eng = model._engine_for(batch)
         out4 = eng.forward(model._flat, model._bn_state, batch, eps, model._pos_weight_dev(),
-                           model.training).clone()
+                           model.training, loss_variant).clone()
         ctx.model, ctx.engine, ctx.generation = model, eng, eng.generation
         rec, kl, max_logit, logvar_max = out4[0], out4[1], out4[2], out4[3]
         ctx.mark_non_differentiable(max_logit, logvar_max)
@@ -102,7 +102,7 @@ class _StepFunction(torch.autograd.Function):
         grads = model._grad_flat_buffer()
         eng.backward(model._flat, model._pos_weight_dev(), grads, 1.0, 1.0, up)
         views = model._views_of(grads)
-        return (None, None, None) + tuple(views)
+        return (None, None, None, None) + tuple(views)
 
 
 class GraphVAE(nn.Module):
@@ -310,16 +310,32 @@ class GraphVAE(nn.Module):
         eps = torch.randn(batch.num_graphs, self.z_dim, dtype=torch.float32, device=batch.device)
         return self.forward_with_eps(batch, eps)
 
-    def forward_with_eps(self, batch: DenseGraphBatch, eps: torch.Tensor) -> dict:
-        """`forward` with caller-supplied reparameterisation noise (one row per graph)."""
+    def forward_with_eps(self, batch: DenseGraphBatch, eps: torch.Tensor, *,
+                         legacy: bool = False) -> dict:
+        """`forward` (or, with legacy=True, `forward_old`) with caller-supplied
+        reparameterisation noise (one row per graph)."""
         if self.rho_global is None:
             raise RuntimeError("Call `model.precompute_dataset_rho(...)` first!")
-        rec, kl, max_logit, logvar_max = _StepFunction.apply(self, batch, eps, *self._named_param_list())
+        variant = LOSS_DUMMY_MASKED if legacy else LOSS_CURRENT
+        rec, kl, max_logit, logvar_max = _StepFunction.apply(self, batch, eps, variant,
+                                                             *self._named_param_list())
         if self.training:
             for bn in (self.bn1, self.bn2):
                 bn.num_batches_tracked += batch.num_graphs
+        if legacy:   # reference model.py:439-440 returns no "loss" entry
+            return {"rec": rec, "kl": kl, "max_logit": max_logit, "logvar_max": logvar_max}
         return {"rec": rec, "kl": kl, "loss": rec + kl, "max_logit": max_logit,
                 "logvar_max": logvar_max}
+
+    def forward_old(self, data):
+        """The older loss kept by the reference (model.py:378-440): as `forward`, except that the
+        node logits of padded entries are overwritten with -10 before the node loss, so padded
+        entries add a constant and get no gradient.  Same kernels, same matching."""
+        if self.rho_global is None:
+            raise RuntimeError("Call `model.precompute_dataset_rho(...)` first!")
+        batch = as_dense_batch(data, self.max_nodes)
+        eps = torch.randn(batch.num_graphs, self.z_dim, dtype=torch.float32, device=batch.device)
+        return self.forward_with_eps(batch, eps, legacy=True)
 
     @torch.no_grad()
     def sample_decode(self, z: torch.Tensor, th_edge: float = 0.5, th_node: float = 0.5) -> dict:

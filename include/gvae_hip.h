@@ -146,6 +146,11 @@ int64_t gvae_param_layout(const gvae_dims *d, int64_t *offsets, int64_t *sizes);
 #define GVAE_MATCH_STREAM 1  /* materialise S, stream it per MPM iteration (HBM)    */
 #define GVAE_MATCH_FUSED 2   /* S-free MPM resident in LDS                          */
 
+#define GVAE_LOSS_CURRENT 0       /* GraphVAE.forward, graphvae/models/model.py:337-343       */
+#define GVAE_LOSS_DUMMY_MASKED 1  /* GraphVAE.forward_old, model.py:403-408,425-427: the node
+                                     logits of padded entries are overwritten with -10 before
+                                     the node loss (constant term, no gradient)               */
+
 /* Bytes of scratch gvae_step_forward/backward need for n_graphs graphs.  The
  * forward leaves its activations there for the backward of the same batch. */
 int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs);
@@ -162,6 +167,7 @@ int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs);
  *   d_R          real nodes per graph;  r_max >= max R (host value)
  *   d_eps        (n_graphs, Z) standard-normal draws for the reparameterisation
  *   d_pos_weight 1 float: the pos_weight_global buffer
+ *   loss_variant GVAE_LOSS_*; the backward of the batch must be given the same value
  *   matching     GVAE_MATCH_*;  STREAM needs d_S and d_S_off (both may be NULL otherwise).
  *                S is kept in the GVAE_S_PADDED layout and may be smaller than the batch's
  *                whole tensor: the graphs are matched in n_chunks consecutive chunks,
@@ -174,8 +180,8 @@ int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs);
  */
 int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
                       const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
-                      int r_max, const float *d_eps, const float *d_pos_weight, int train,
-                      int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                      int r_max, const float *d_eps, const float *d_pos_weight, int loss_variant,
+                      int train, int matching, int mpm_iters, float tol, int early_stop, float *d_S,
                       const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
                       void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
                       void *stream);
@@ -187,8 +193,8 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
  * overwritten (flat, same layout as the parameters; padding floats untouched). */
 int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d_x,
                        const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
-                       const float *d_eps, const float *d_pos_weight, float c_rec, float c_kl,
-                       const float *d_up, void *d_ws, float *d_grads, void *stream);
+                       const float *d_eps, const float *d_pos_weight, int loss_variant, float c_rec,
+                       float c_kl, const float *d_up, void *d_ws, float *d_grads, void *stream);
 
 /* Pointer into the workspace for inspection by tests: which = 0 edge logits (B,U),
  * 1 node logits (B,N), 2 P (B,N,N), 3 X (B,N,N), 4 mu, 5 logvar (pre-clamp) (B,Z),

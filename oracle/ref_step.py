@@ -146,9 +146,13 @@ def vec_to_adj(vec, N):
 
 def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: float = 0.1,
                   mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
-                  no_grad_matching: bool = False):
+                  no_grad_matching: bool = False, legacy_mask: bool = False):
     """One graph through reference model.py:288-366.  `g` has x (n_x,F), adj_dense (N,N),
-    num_real_nodes.  Mutates the BN running statistics in `st` when train."""
+    num_real_nodes.  Mutates the BN running statistics in `st` when train.
+    `legacy_mask` selects the older loss `forward_old` (model.py:403-408,425-427): the logits
+    of padded nodes are overwritten with -10 before the node loss, so they contribute the
+    constant softplus(-10) each and receive no gradient; everything else is unchanged (the
+    R x R block handed to the matching is not touched by the overwrite)."""
     N = g.adj_dense.size(0)
     R = int(g.num_real_nodes)
     A_gt = g.adj_dense
@@ -200,7 +204,8 @@ def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: floa
     node_truth = torch.zeros(N)
     node_truth[:R] = 1.0
     pos_w_node = torch.tensor((N - R) / (R + 1e-8)).clamp(1.0, 5.0)
-    loss_nodes = F.binary_cross_entropy_with_logits(node_logits, node_truth, pos_weight=pos_w_node)
+    node_in = torch.cat([node_logits[:R], torch.full((N - R,), -10.0)]) if legacy_mask else node_logits
+    loss_nodes = F.binary_cross_entropy_with_logits(node_in, node_truth, pos_weight=pos_w_node)
     node_masked = node_logits.detach().clone()
     node_masked[R:] = -10.0
     max_logit = torch.cat([vec_logits.detach(), node_masked]).abs().max()

@@ -33,6 +33,16 @@ def load_g5(path):
                            rho=float(g["rho"]))
 
 
+def load_g10(golden_dir):
+    """The `forward_old` fixture (outputs only) with the g5 rand/deg case it was generated on."""
+    G = load_g5(golden_dir / "g5_forward_rand_deg.npz")
+    g = np.load(golden_dir / "g10_forward_old_rand_deg.npz", allow_pickle=False)
+    out = {k[len("out/"):]: g[k] for k in g.files if k.startswith("out/")}
+    grads = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    perms = [g[f"g{i}/perm"] for i in range(len(G.graphs))]
+    return G, SimpleNamespace(out=out, grads=grads, perms=perms)
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
@@ -41,7 +51,7 @@ def rel_err(a, b):
 ZERO_GRAD_PARAMS = ("conv1.bias", "conv2.bias")
 
 
-def truth64(G):
+def truth64(G, **kw):
     """Loss and gradients of the golden case recomputed in float64 by the CPU
     restatement: the yardstick for how far the fp32 reference itself is from the exact
     answer (BatchNorm over a handful of near-identical rows is ill-conditioned)."""
@@ -53,7 +63,7 @@ def truth64(G):
                                for k, v in G.state0.items()})
         graphs = [SimpleNamespace(x=g.x.double(), adj_dense=g.adj_dense.double(),
                                   num_real_nodes=g.num_real_nodes) for g in G.graphs]
-        res = R.forward_batch(st, graphs, [e.double() for e in G.eps], train=True)
+        res = R.forward_batch(st, graphs, [e.double() for e in G.eps], train=True, **kw)
         res.loss.backward()
         return {n: st[n].grad.numpy().copy() for n in R.PARAM_NAMES}
     finally:

@@ -11,12 +11,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import (check_grads, check_params_after_adam, load_g5, perm_equivalent,  # noqa: E402
-                         rel_err, truth64)
+from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10,  # noqa: E402
+                         perm_equivalent, rel_err, truth64)
 from oracle import ref_step as R  # noqa: E402  (checker only)
 
 CASES = ["grid_deg", "grid_id", "rand_deg", "rand_id"]
 TOL = 1e-5
+# conv1.lin.weight of the legacy-loss case is a (H, 1) tensor whose entries are sums with heavy
+# cancellation once the padded node logits stop contributing: fp32 evaluations of the same
+# formula differ by ~4e-5 of its scale (the reference sits 6e-6 from the float64 value).
+LEGACY_GRAD_TOL = 5e-5
 DEV = "cuda:0"
 # Gradient tolerance per golden case.  grid/deg contains the 2x2 grid graph, whose four
 # real nodes are all equivalent: a layer-2 BatchNorm column there has variance 1.3e-5 (about
@@ -133,6 +137,33 @@ def test_three_optimizer_steps_vs_reference_golden(golden_dir, case):
         assert abs(step.grad_norm.item() - ref[3]) <= gn_tol * abs(ref[3]), (gs, step.grad_norm.item(), ref[3])
     got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     check_params_after_adam(got, G.opt["state3"], lr, tol=1e-4 if case not in GRAD_TOL else 5e-3)
+
+
+@pytest.mark.parametrize("matching", ["fused", "stream"])
+def test_forward_old_vs_reference_golden(golden_dir, matching):
+    """The legacy loss (reference model.py:378-440) on a batch with padded nodes: losses,
+    permutations and every parameter gradient against the imported reference's."""
+    G, L = load_g10(golden_dir)
+    model, batch, eps = _model_and_batch(G, matching)
+    model.train()
+    out = model.forward_with_eps(batch, eps, legacy=True)
+    assert "loss" not in out
+    for k in ("rec", "kl", "max_logit", "logvar_max"):
+        assert rel_err(out[k].item(), L.out[k]) < TOL, (k, out[k].item(), L.out[k])
+    B = batch.num_graphs
+    assert rel_err(model._engine.debug_tensor("rec_i", B).cpu().numpy(), L.out["rec_i"]) < TOL
+    X = model._engine.debug_tensor("X", B).cpu().numpy()
+    perm = model.last_permutations().cpu().numpy()
+    for g, p in enumerate(L.perms):
+        assert perm_equivalent(perm[g, :len(p)], p, X[g])
+    (out["rec"] + out["kl"]).backward()
+    got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
+    check_grads(got, L.grads, truth64(G, legacy_mask=True), LEGACY_GRAD_TOL)
+    # padded node logits get no gradient: rows of dec_node.2 beyond the largest graph... every
+    # graph of this batch has R <= N, and the two with R == N have no padded entry at all
+    torch.manual_seed(0)
+    out2 = model.forward_old(batch)
+    assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
 
 
 def test_autograd_path_equals_fused_step_path(golden_dir):

@@ -10,10 +10,15 @@ import torch
 
 from oracle import ref_step as R
 from oracle import matching as ora
-from golden_util import check_grads, check_params_after_adam, load_g5, perm_equivalent, rel_err, truth64
+from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10, perm_equivalent,
+                         rel_err, truth64)
 
 CASES = ["grid_deg", "grid_id", "rand_deg", "rand_id"]
 TOL = 1e-5
+# conv1.lin.weight of the legacy-loss case is a (H, 1) tensor whose entries are sums with heavy
+# cancellation once the padded node logits stop contributing: fp32 evaluations of the same
+# formula differ by ~4e-5 of its scale (the reference sits 6e-6 from the float64 value).
+LEGACY_GRAD_TOL = 5e-5
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -69,3 +74,19 @@ def test_three_optimizer_steps(golden_dir, case):
         assert abs(loss - ref[0]) <= 2e-5 * abs(ref[0]), (gs, loss, ref[0])
         assert abs(gn - ref[3]) <= 1e-4 * abs(ref[3]), (gs, gn, ref[3])
     check_params_after_adam({k: st[k].detach().numpy() for k in R.PARAM_NAMES}, G.opt["state3"], lr)
+
+
+def test_legacy_loss_matches_reference_forward_old(golden_dir):
+    """`forward_old` (reference model.py:378-440): padded node logits read as -10."""
+    G, L = load_g10(golden_dir)
+    st = R.make_trainable(G.state0)
+    res = R.forward_batch(st, G.graphs, G.eps, train=True, legacy_mask=True)
+    for k in ("rec", "kl", "max_logit", "logvar_max"):
+        assert rel_err(getattr(res, k).detach().numpy(), L.out[k]) < TOL, k
+    assert rel_err(torch.stack([o.rec for o in res.per_graph]).detach().numpy(), L.out["rec_i"]) < TOL
+    assert abs(float(res.rec) - float(G.out["rec"])) > 0.1      # the variant is not a no-op here
+    for o, p in zip(res.per_graph, L.perms):
+        assert perm_equivalent(o.perm[:len(p)].numpy(), p, o.X.numpy())
+    (res.rec + res.kl).backward()
+    check_grads({n: st[n].grad.numpy() for n in R.PARAM_NAMES}, L.grads,
+                truth64(G, legacy_mask=True), LEGACY_GRAD_TOL)

@@ -54,6 +54,35 @@ def test_metrics_match_networkx():
         assert np.allclose(degree_histogram(a), ref / ref.sum())
 
 
+def test_path_length_and_degree_distance_match_networkx():
+    """aspl / degree_l1 / batch_stat (reference eval/metrics.py:22-28,38-51 restated with
+    networkx calls here; sparse graphs so that several components and isolated nodes occur)."""
+    nx = pytest.importorskip("networkx")
+    from graphvae.eval.metrics import aspl, batch_stat, degree_histogram, degree_l1
+
+    def ref_aspl(g):
+        if nx.is_connected(g):
+            return nx.average_shortest_path_length(g)
+        comps = [g.subgraph(c) for c in nx.connected_components(g)]
+        return float(np.average([nx.average_shortest_path_length(c) for c in comps],
+                                weights=[len(c) for c in comps]))
+
+    graphs = [nx.erdos_renyi_graph(16, p, seed=s) for s, p in enumerate((0.08, 0.12, 0.2, 0.5))]
+    graphs.append(nx.path_graph(7))
+    assert any(not nx.is_connected(g) for g in graphs)
+    for g in graphs:
+        assert abs(aspl(nx.to_numpy_array(g)) - ref_aspl(g)) < 1e-12
+        assert abs(aspl(g) - ref_aspl(g)) < 1e-12
+    assert abs(batch_stat(aspl, graphs) - np.mean([ref_aspl(g) for g in graphs])) < 1e-12
+    for g1, g2 in zip(graphs[:-1], graphs[1:]):
+        h1, h2 = degree_histogram(g1), degree_histogram(g2, len(degree_histogram(g1)) - 1)
+        m = max(len(h1), len(h2))
+        want = np.abs(np.pad(h1, (0, m - len(h1))) - np.pad(h2, (0, m - len(h2)))).sum() / 2.0
+        assert abs(degree_l1(g1, g2) - want) < 1e-7
+        assert 0.0 <= degree_l1(g1, g2) <= 1.0
+    assert degree_l1(graphs[0], graphs[0]) == 0.0
+
+
 def _near_threshold(logits, th, width=1e-5):
     p = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
     return np.abs(p - th) < width

@@ -322,8 +322,9 @@ def graphs_for_forward(kind: str):
     return gs, 12
 
 
-def run_reference_step(ref, model, graphs, eps_list, train: bool):
-    """One reference forward over a list of single-graph inputs, reproducing the
+def run_reference_step(ref, model, graphs, eps_list, train: bool, method: str = "forward"):
+    """One reference forward (`forward`, or the legacy `forward_old`, model.py:378-440)
+    over a list of single-graph inputs, reproducing the
     batch reduction of model.py:368-373 (a `Batch` cannot be built without PyG,
     so graphs are fed one at a time through the `else [data]` branch and the
     per-graph losses are averaged exactly as forward does for a batch)."""
@@ -361,7 +362,7 @@ def run_reference_step(ref, model, graphs, eps_list, train: bool):
     torch.randn_like = fixed_randn_like
     try:
         model.train(train)
-        outs = [model(g) for g in graphs]
+        outs = [model(g) if method == "forward" else getattr(model, method)(g) for g in graphs]
     finally:
         scipy.optimize.linear_sum_assignment = orig_lsa
         torch.randn_like = orig_randn_like
@@ -465,6 +466,41 @@ def gen_forward(ref, out: Path):
               f"kl={res['kl'].item():.6f} opt losses={[round(l[0], 5) for l in losses]}")
 
 
+def gen_forward_old(ref, out: Path):
+    """G10: the legacy loss `forward_old` (reference model.py:378-440) on the rand/deg graphs
+    of G5, from the same initial state and the same noise: losses, permutations and all
+    parameter gradients.  Inputs are not stored again; the fixture records checksums of the
+    G5 inputs it was generated from."""
+    kind, ftype = "rand", "deg"
+    nxg, N = graphs_for_forward(kind)
+    graphs = [nx_to_graph(g, N, ftype) for g in nxg]
+    H, Z = 16, 8
+    base = np.load(out / f"g5_forward_{kind}_{ftype}.npz")
+    torch.manual_seed(42)
+    model = ref.GraphVAE(1, H, Z, N)
+    model.load_state_dict({k[len("state0/"):]: torch.from_numpy(base[k].copy())
+                           for k in base.files if k.startswith("state0/")})
+    model.rho_global = float(base["rho"])
+    eps = [torch.from_numpy(base[f"g{i}/eps"].copy()) for i in range(len(graphs))]
+    for i, g in enumerate(graphs):
+        assert np.array_equal(base[f"g{i}/adj_dense"], g.adj_dense.numpy())
+    res, perms = run_reference_step(ref, model, graphs, eps, train=True, method="forward_old")
+    (res["rec"] + res["kl"]).backward()
+    store = {"meta": np.array("forward_old on the inputs, initial state and noise of g5_forward_rand_deg"),
+             "inputs_sha": np.array(sha(np.concatenate([base[f"g{i}/adj_dense"].ravel()
+                                                        for i in range(len(graphs))])))}
+    for k in ("rec", "kl", "max_logit", "logvar_max", "rec_i", "kl_i"):
+        store[f"out/{k}"] = res[k].detach().numpy()
+    for i, p in enumerate(perms):
+        store[f"g{i}/perm"] = p
+    for n_, p in model.named_parameters():
+        store[f"grad/{n_}"] = p.grad.numpy().copy()
+    np.savez_compressed(out / "g10_forward_old_rand_deg.npz", **store)
+    d = float(res["rec"]) - float(base["out/rec"])
+    print(f"G10 forward_old rand/deg: rec={res['rec'].item():.6f} (forward: {float(base['out/rec']):.6f}, "
+          f"diff {d:+.3e}) kl={res['kl'].item():.6f}")
+
+
 def gen_rho(ref, out: Path):
     """precompute_dataset_rho (reference model.py:99-118) on the grid graphs."""
     nxg, N = graphs_for_forward("grid")
@@ -542,7 +578,7 @@ def gen_sampler(ref, out: Path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(Path(__file__).resolve().parents[1] / "tests" / "golden"))
-    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler)")
+    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler | forward_old)")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
@@ -551,11 +587,15 @@ def main():
     if args.only == "sampler":
         gen_sampler(ref, out)
         return
+    if args.only == "forward_old":
+        gen_forward_old(ref, out)
+        return
     gen_forward_test(ref, out)
     gen_reduction_orders(out)
     gen_lsap(out)
     gen_rho(ref, out)
     gen_forward(ref, out)
+    gen_forward_old(ref, out)
     gen_matching(ref, out)
     gen_sampler(ref, out)
 
