@@ -288,34 +288,12 @@ int64_t gvae_step_ws_bytes(const gvae_dims *d, int n_graphs) {
     if (rc_) return rc_;  \
   } while (0)
 
-int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
-                      const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
-                      int r_max, const float *d_eps, const float *d_pos_weight, int loss_variant,
-                      int train, int matching, int mpm_iters, float tol, int early_stop, float *d_S,
-                      const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
-                      void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
-                      void *stream) {
-  GVAE_REQUIRE(d && d_params && d_bn_state && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight &&
-                   d_ws && d_out4 && d_perm && d_iters_done,
-               GVAE_EINVAL, "step_forward: null pointer");
-  GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535 && r_max > 0 && r_max <= d->N, GVAE_EINVAL,
-               "step_forward: bad sizes (n_graphs=%d r_max=%d N=%d)", n_graphs, r_max, d->N);
-  GVAE_REQUIRE(matching >= GVAE_MATCH_NONE && matching <= GVAE_MATCH_FUSED, GVAE_EINVAL,
-               "step_forward: unknown matching mode %d", matching);
-  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
-               GVAE_EINVAL, "step_forward: unknown loss variant %d", loss_variant);
-  GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
-               "step_forward: streaming matching needs the S buffer and its offsets");
-  GVAE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || h_chunk_begin), GVAE_EINVAL,
-               "step_forward: bad chunk list");
-  if (n_chunks > 0) {
-    GVAE_REQUIRE(h_chunk_begin[0] == 0 && h_chunk_begin[n_chunks] == n_graphs, GVAE_EINVAL,
-                 "step_forward: chunks must cover graphs 0..%d", n_graphs);
-    for (int c = 0; c < n_chunks; ++c)
-      GVAE_REQUIRE(h_chunk_begin[c] < h_chunk_begin[c + 1], GVAE_EINVAL,
-                   "step_forward: chunk %d is empty or out of order", c);
-  }
-  hipStream_t s = (hipStream_t)stream;
+// Encoder, heads, reparameterisation and decoder: everything of the forward that the
+// backward needs (model.py:295-303).
+static int forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,
+                         const float *d_x, const float *d_adj, const int32_t *d_n_x,
+                         const int32_t *d_R, int n_graphs, const float *d_eps, int train, void *d_ws,
+                         hipStream_t s) {
   const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
   const Workspace w = carve(d, B, (char *)d_ws);
   const Params P = bind(d, d_params);
@@ -356,6 +334,20 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
         desc_linear_fwd(w.hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], w.node, B, N, H, 0)};
     TRY(launch_gemm_group(l2, 2, w.splitk, w.splitk_floats, s));
   }
+  return 0;
+}
+
+// Matching, assignment and the losses (model.py:305-373).  Reads the logits, mu and logvar the
+// model part left in the workspace and writes only buffers the backward never touches, so it
+// may run on another stream, concurrently with the backward of the same batch.
+static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int32_t *d_R,
+                              int n_graphs, int r_max, const float *d_pos_weight, int loss_variant,
+                              int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                              const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
+                              void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                              hipStream_t s) {
+  const int B = n_graphs, Z = d->Z, N = d->N;
+  const Workspace w = carve(d, B, (char *)d_ws);
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
     hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
@@ -388,7 +380,80 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
   // losses (model.py:325-373)
   TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,
                       loss_variant == GVAE_LOSS_DUMMY_MASKED, w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
+  return 0;
+}
+
+static int check_match_args(const gvae_dims *d, int n_graphs, int r_max, int loss_variant,
+                            int matching, const float *d_S, const int64_t *d_S_off,
+                            const int32_t *h_chunk_begin, int n_chunks, const char *who) {
+  GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535 && r_max > 0 && r_max <= d->N, GVAE_EINVAL,
+               "%s: bad sizes (n_graphs=%d r_max=%d N=%d)", who, n_graphs, r_max, d->N);
+  GVAE_REQUIRE(matching >= GVAE_MATCH_NONE && matching <= GVAE_MATCH_FUSED, GVAE_EINVAL,
+               "%s: unknown matching mode %d", who, matching);
+  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
+               GVAE_EINVAL, "%s: unknown loss variant %d", who, loss_variant);
+  GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
+               "%s: streaming matching needs the S buffer and its offsets", who);
+  GVAE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || h_chunk_begin), GVAE_EINVAL, "%s: bad chunk list",
+               who);
+  if (n_chunks > 0) {
+    GVAE_REQUIRE(h_chunk_begin[0] == 0 && h_chunk_begin[n_chunks] == n_graphs, GVAE_EINVAL,
+                 "%s: chunks must cover graphs 0..%d", who, n_graphs);
+    for (int c = 0; c < n_chunks; ++c)
+      GVAE_REQUIRE(h_chunk_begin[c] < h_chunk_begin[c + 1], GVAE_EINVAL,
+                   "%s: chunk %d is empty or out of order", who, c);
+  }
+  return 0;
+}
+
+int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_state, const float *d_x,
+                      const float *d_adj, const int32_t *d_n_x, const int32_t *d_R, int n_graphs,
+                      int r_max, const float *d_eps, const float *d_pos_weight, int loss_variant,
+                      int train, int matching, int mpm_iters, float tol, int early_stop, float *d_S,
+                      const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
+                      void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                      void *stream) {
+  GVAE_REQUIRE(d && d_params && d_bn_state && d_x && d_adj && d_n_x && d_R && d_eps && d_pos_weight &&
+                   d_ws && d_out4 && d_perm && d_iters_done,
+               GVAE_EINVAL, "step_forward: null pointer");
+  TRY(check_match_args(d, n_graphs, r_max, loss_variant, matching, d_S, d_S_off, h_chunk_begin,
+                       n_chunks, "step_forward"));
+  hipStream_t s = (hipStream_t)stream;
+  TRY(forward_model(d, d_params, d_bn_state, d_x, d_adj, d_n_x, d_R, n_graphs, d_eps, train, d_ws, s));
+  TRY(forward_match_loss(d, d_adj, d_R, n_graphs, r_max, d_pos_weight, loss_variant, matching,
+                         mpm_iters, tol, early_stop, d_S, d_S_off, h_chunk_begin, n_chunks, d_ws,
+                         d_out4, d_perm, d_iters_done, s));
   return check_launch("step_forward");
+}
+
+int gvae_step_forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,
+                            const float *d_x, const float *d_adj, const int32_t *d_n_x,
+                            const int32_t *d_R, int n_graphs, const float *d_eps, int train,
+                            void *d_ws, void *stream) {
+  GVAE_REQUIRE(d && d_params && d_bn_state && d_x && d_adj && d_n_x && d_R && d_eps && d_ws,
+               GVAE_EINVAL, "step_forward_model: null pointer");
+  GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535, GVAE_EINVAL,
+               "step_forward_model: bad n_graphs=%d", n_graphs);
+  TRY(forward_model(d, d_params, d_bn_state, d_x, d_adj, d_n_x, d_R, n_graphs, d_eps, train, d_ws,
+                    (hipStream_t)stream));
+  return check_launch("step_forward_model");
+}
+
+int gvae_step_forward_match_loss(const gvae_dims *d, const float *d_adj, const int32_t *d_R,
+                                 int n_graphs, int r_max, const float *d_pos_weight,
+                                 int loss_variant, int matching, int mpm_iters, float tol,
+                                 int early_stop, float *d_S, const int64_t *d_S_off,
+                                 const int32_t *h_chunk_begin, int n_chunks, void *d_ws,
+                                 float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                                 void *stream) {
+  GVAE_REQUIRE(d && d_adj && d_R && d_pos_weight && d_ws && d_out4 && d_perm && d_iters_done,
+               GVAE_EINVAL, "step_forward_match_loss: null pointer");
+  TRY(check_match_args(d, n_graphs, r_max, loss_variant, matching, d_S, d_S_off, h_chunk_begin,
+                       n_chunks, "step_forward_match_loss"));
+  TRY(forward_match_loss(d, d_adj, d_R, n_graphs, r_max, d_pos_weight, loss_variant, matching,
+                         mpm_iters, tol, early_stop, d_S, d_S_off, h_chunk_begin, n_chunks, d_ws,
+                         d_out4, d_perm, d_iters_done, (hipStream_t)stream));
+  return check_launch("step_forward_match_loss");
 }
 
 int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d_x,

@@ -51,6 +51,13 @@ def _bind():
     L.gvae_step_backward.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p]
+    L.gvae_step_forward_model.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p]
+    L.gvae_step_forward_match_loss.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_int, c_int,
+                                               c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                               c_void_p, c_void_p, POINTER(c_int32), c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]
     L.gvae_step_read_debug.argtypes = [POINTER(Dims), c_int, c_void_p, c_int, POINTER(c_void_p),
                                        POINTER(c_int64)]
     L.gvae_adam_ws_bytes.restype = c_int64
@@ -138,6 +145,7 @@ class StepEngine:
         self.iters_done = None
         self.generation = 0
         self._fwd_batch = None
+        self._pending = None
         self.last_mode = MATCH_NONE
 
     # ------------------------------------------------------------------ helpers
@@ -182,15 +190,7 @@ class StepEngine:
             raise _hip.GvaeHipError("batch.r_host must list 1 <= R <= max_nodes for every graph")
 
     # ------------------------------------------------------------------ step pieces
-    def forward(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,
-                eps: torch.Tensor, pos_weight: torch.Tensor, train: bool,
-                loss_variant: int = LOSS_CURRENT) -> torch.Tensor:
-        """Runs the forward; returns the device tensor [rec, kl, max_logit, logvar_max]
-        (a view of engine memory, overwritten by the next forward).  `loss_variant`:
-        LOSS_CURRENT (reference model.py:281-373) or LOSS_DUMMY_MASKED (`forward_old`,
-        model.py:378-440); the backward of this batch uses the same variant."""
-        if loss_variant not in (LOSS_CURRENT, LOSS_DUMMY_MASKED):
-            raise ValueError(f"unknown loss variant {loss_variant}")
+    def _prepare(self, params, bn_state, batch, eps, pos_weight, loss_variant):
         self._check_batch(batch)
         B = batch.num_graphs
         self._ensure(B)
@@ -198,23 +198,71 @@ class StepEngine:
         _hip._dev(eps, torch.float32), _hip._dev(pos_weight, torch.float32)
         if tuple(eps.shape) != (B, self.Z):
             raise _hip.GvaeHipError(f"eps must be ({B}, {self.Z})")
+        if loss_variant not in (LOSS_CURRENT, LOSS_DUMMY_MASKED):
+            raise ValueError(f"unknown loss variant {loss_variant}")
         r_max = max(batch.r_host)
-        mode = self.resolve_matching(r_max)
-        S_ptr, Soff_ptr, chunks, n_chunks = None, None, None, 0
-        if mode == MATCH_STREAM:
-            self._ensure_S(batch.r_host)
-            S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()
-            chunks, n_chunks = self._S_chunks, len(self._S_chunks) - 1
+        return B, r_max, self.resolve_matching(r_max)
+
+    def _S_args(self, mode: int, batch: DenseGraphBatch):
+        if mode != MATCH_STREAM:
+            return None, None, None, 0
+        self._ensure_S(batch.r_host)
+        return (self._S.data_ptr(), self._S_off.data_ptr(), self._S_chunks, len(self._S_chunks) - 1)
+
+    def forward(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,
+                eps: torch.Tensor, pos_weight: torch.Tensor, train: bool,
+                loss_variant: int = LOSS_CURRENT) -> torch.Tensor:
+        """Runs the forward; returns the device tensor [rec, kl, max_logit, logvar_max]
+        (a view of engine memory, overwritten by the next forward).  `loss_variant`:
+        LOSS_CURRENT (reference model.py:281-373) or LOSS_DUMMY_MASKED (`forward_old`,
+        model.py:378-440); the backward of this batch uses the same variant."""
+        B, r_max, mode = self._prepare(params, bn_state, batch, eps, pos_weight, loss_variant)
+        S_ptr, Soff_ptr, chunks, n_chunks = self._S_args(mode, batch)
         _hip._check(self.L.gvae_step_forward(
             ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
             batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B, r_max,
-            eps.data_ptr(), pos_weight.data_ptr(), int(loss_variant), int(train), mode, self.mpm_iters, self.tol,
-            int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
+            eps.data_ptr(), pos_weight.data_ptr(), int(loss_variant), int(train), mode, self.mpm_iters,
+            self.tol, int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
             self.out4.data_ptr(),
             self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
         self.generation += 1
         self._fwd_batch = (batch, eps, int(loss_variant))
         self.last_mode = mode
+        return self.out4
+
+    def forward_model(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,
+                      eps: torch.Tensor, pos_weight: torch.Tensor, train: bool,
+                      loss_variant: int = LOSS_CURRENT) -> None:
+        """First half of `forward` (encoder, heads, decoder) on the current stream: all that
+        `backward` needs.  `forward_match_loss` must follow for the same batch, on this or on
+        another stream ordered behind this call."""
+        B, r_max, mode = self._prepare(params, bn_state, batch, eps, pos_weight, loss_variant)
+        _hip._check(self.L.gvae_step_forward_model(
+            ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
+            batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B,
+            eps.data_ptr(), int(train), self._ws.data_ptr(), _hip._stream()))
+        self.generation += 1
+        self._fwd_batch = (batch, eps, int(loss_variant))
+        self._pending = (B, r_max, mode, pos_weight)
+        self.last_mode = mode
+
+    def forward_match_loss(self) -> torch.Tensor:
+        """Second half of `forward` (matching, assignment, losses) for the batch of the last
+        `forward_model`, enqueued on the CURRENT stream; returns the device tensor
+        [rec, kl, max_logit, logvar_max] (engine memory).  The parameter gradients do not
+        depend on the permutation (reference model.py:325-334 gathers prediction and truth
+        through the same permutation), so this may run concurrently with `backward`."""
+        if getattr(self, "_pending", None) is None:
+            raise _hip.GvaeHipError("forward_match_loss called without a forward_model before it")
+        B, r_max, mode, pos_weight = self._pending
+        batch, _eps, loss_variant = self._fwd_batch
+        self._pending = None
+        S_ptr, Soff_ptr, chunks, n_chunks = self._S_args(mode, batch)
+        _hip._check(self.L.gvae_step_forward_match_loss(
+            ctypes.byref(self.dims), batch.adj_dense.data_ptr(), batch.num_real_nodes.data_ptr(), B,
+            r_max, pos_weight.data_ptr(), loss_variant, mode, self.mpm_iters, self.tol,
+            int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
+            self.out4.data_ptr(), self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
         return self.out4
 
     def backward(self, params: torch.Tensor, pos_weight: torch.Tensor, grads: torch.Tensor,

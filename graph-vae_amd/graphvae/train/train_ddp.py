@@ -139,7 +139,7 @@ class TrainStep:
 
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
                  world: int = 1, group=None, sync_bn_buffers: bool = False, engine=None,
-                 force_collectives: bool = False) -> None:
+                 force_collectives: bool = False, overlap_matching: bool = True) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
         model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
         `sync_bn_buffers`: broadcast rank 0's BatchNorm running statistics before every forward,
@@ -148,7 +148,13 @@ class TrainStep:
         broadcast is left to `sync_buffers()`, which the trainer calls before validation and
         before saving: same statistics wherever they are read, one collective fewer per step.
         `force_collectives`: issue the step's collectives even in a group of one rank (a
-        single-GPU rehearsal of the stream ordering between RCCL and the HIP kernels)."""
+        single-GPU rehearsal of the stream ordering between RCCL and the HIP kernels).
+        `overlap_matching`: run matching + assignment + losses on a second HIP stream while the
+        backward, the all-reduce and Adam run on the current one.  The gradients do not depend
+        on the permutation (reference model.py:325-334 gathers prediction and ground truth
+        through the same perm_full, so the edge loss visits each pair of real nodes exactly
+        once), hence both halves only need the decoder's logits; they are joined before the
+        step returns.  Results are bit-identical to the sequential order."""
         self.model = model
         self._engine = engine
         self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
@@ -156,6 +162,9 @@ class TrainStep:
         self.sync_bn_buffers = sync_bn_buffers
         self.collectives = world > 1 or force_collectives
         flat = model.flat_parameters()
+        self.overlap_matching = bool(overlap_matching) and flat.is_cuda
+        self._side = None       # second stream + events, created on first use
+        self._ev_model = self._ev_match = None
         self.grads = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
@@ -178,8 +187,23 @@ class TrainStep:
         eng = self._engine if self._engine is not None else model._engine_for(batch)
         if eps is None:
             eps = torch.randn(batch.num_graphs, model.z_dim, dtype=torch.float32, device=batch.device)
-        out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
-                           model._pos_weight_dev(), True).clone()
+        overlap = self.overlap_matching and hasattr(eng, "forward_match_loss")
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.grads.device)
+                self._ev_model, self._ev_match = torch.cuda.Event(), torch.cuda.Event()
+            main = torch.cuda.current_stream(self.grads.device)
+            eng.forward_model(model.flat_parameters(), model.bn_state(), batch, eps,
+                              model._pos_weight_dev(), True)
+            self._ev_model.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_model)
+                out4 = eng.forward_match_loss().clone()
+                self._ev_match.record(self._side)
+            out4.record_stream(main)
+        else:
+            out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
+                               model._pos_weight_dev(), True).clone()
         eng.backward(model.flat_parameters(), model._pos_weight_dev(), self.grads, 1.0, beta)
         if self.collectives:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -187,6 +211,10 @@ class TrainStep:
         eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
                       self.lr * lr_scale, weight_decay=self.weight_decay, clip_max=self.clip_max,
                       grad_scale=1.0 / self.world, norm_out=self.grad_norm)
+        if overlap:
+            # join: what follows on this stream (the caller reading the losses, the next forward
+            # overwriting the workspace) is ordered behind the matching half
+            torch.cuda.current_stream(self.grads.device).wait_event(self._ev_match)
         for bn in (model.bn1, model.bn2):
             bn.num_batches_tracked += batch.num_graphs
         return out4

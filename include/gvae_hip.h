@@ -186,6 +186,31 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
                       void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
                       void *stream);
 
+/* The same forward in two calls, for callers that overlap the matching with the backward.
+ * The parameter gradients do not depend on the permutation: in model.py:325-334 prediction and
+ * ground truth are gathered through the same perm_full, so the edge loss visits every pair of
+ * real nodes exactly once whatever the assignment.  The backward therefore only needs what
+ *   gvae_step_forward_model       encoder, heads, reparameterisation, decoder
+ *                                 (model.py:295-303)
+ * leaves in the workspace, and
+ *   gvae_step_forward_match_loss  matching, assignment, losses, diagnostics (model.py:305-373)
+ * may be enqueued on a second stream (after an event recorded behind the model part),
+ * concurrently with gvae_step_backward of the same batch: it reads the logits, mu and logvar
+ * and writes only buffers the backward never touches.  The caller joins the two streams
+ * before it reads d_out4 / d_perm and before the next forward reuses the workspace.
+ * Arguments as in gvae_step_forward. */
+int gvae_step_forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,
+                            const float *d_x, const float *d_adj, const int32_t *d_n_x,
+                            const int32_t *d_R, int n_graphs, const float *d_eps, int train,
+                            void *d_ws, void *stream);
+int gvae_step_forward_match_loss(const gvae_dims *d, const float *d_adj, const int32_t *d_R,
+                                 int n_graphs, int r_max, const float *d_pos_weight,
+                                 int loss_variant, int matching, int mpm_iters, float tol,
+                                 int early_stop, float *d_S, const int64_t *d_S_off,
+                                 const int32_t *h_chunk_begin, int n_chunks, void *d_ws,
+                                 float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
+                                 void *stream);
+
 /* Backward of  c_rec*up[0]*rec + c_kl*up[1]*kl  with respect to every parameter
  * (what loss.backward() does in graphvae/train/train_ddp.py:283-291, where
  * c_rec = 1 and c_kl = beta).  d_up may be NULL (= ones) or 2 device floats.

@@ -140,6 +140,40 @@ def test_three_optimizer_steps_vs_reference_golden(golden_dir, case):
 
 
 @pytest.mark.parametrize("matching", ["fused", "stream"])
+def test_overlapped_matching_equals_sequential_step(matching):
+    """TrainStep with the matching half on a second stream (concurrent with backward and Adam)
+    against the same steps in stream order: losses, permutations, iteration counts and the
+    parameters after several steps must be bit-identical."""
+    from graphvae.data import synthetic_batch
+    from graphvae.models import GraphVAE
+    from graphvae.train.train_ddp import TrainStep
+    N, B = 32, 48
+    host = [synthetic_batch("enzymes", B, N, "deg", seed=s) for s in (3, 4)]
+    runs = []
+    for overlap in (False, True):
+        torch.manual_seed(42)
+        model = GraphVAE(1, 64, 32, N, matching=matching)
+        model.precompute_dataset_rho(host)
+        model = model.to(DEV).train()
+        step = TrainStep(model, 1e-2, 1e-4, 5.0, overlap_matching=overlap)
+        assert step.overlap_matching == overlap
+        gen = torch.Generator(device="cpu").manual_seed(9)
+        outs, perms, iters = [], [], []
+        for s in range(5):
+            batch = host[s % 2].to(DEV)
+            eps = torch.randn(B, 32, generator=gen).to(DEV)
+            outs.append(step(batch, 0.5, 1.0, eps=eps).cpu())
+            perms.append(model.last_permutations().cpu())
+            iters.append(model.last_mpm_iterations().cpu())
+        model._engine.check_matching()
+        runs.append((torch.stack(outs), torch.stack(perms), torch.stack(iters),
+                     model.flat_parameters().detach().cpu().clone(), model.bn_state().cpu().clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert int(runs[0][2].min()) >= 1
+
+
+@pytest.mark.parametrize("matching", ["fused", "stream"])
 def test_forward_old_vs_reference_golden(golden_dir, matching):
     """The legacy loss (reference model.py:378-440) on a batch with padded nodes: losses,
     permutations and every parameter gradient against the imported reference's."""
@@ -159,8 +193,6 @@ def test_forward_old_vs_reference_golden(golden_dir, matching):
     (out["rec"] + out["kl"]).backward()
     got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
     check_grads(got, L.grads, truth64(G, legacy_mask=True), LEGACY_GRAD_TOL)
-    # padded node logits get no gradient: rows of dec_node.2 beyond the largest graph... every
-    # graph of this batch has R <= N, and the two with R == N have no padded entry at all
     torch.manual_seed(0)
     out2 = model.forward_old(batch)
     assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
