@@ -190,7 +190,11 @@ class TrainStep:
         overlap = self.overlap_matching and hasattr(eng, "forward_match_loss")
         if overlap:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.grads.device)
+                # high priority: the matching half is the step's critical path, and streams of
+                # another priority class never share a hardware queue with the current stream
+                # (with RCCL initialised, a default-priority stream created here ended up behind
+                # the current stream's packets and the two halves ran one after the other)
+                self._side = torch.cuda.Stream(device=self.grads.device, priority=-1)
                 self._ev_model, self._ev_match = torch.cuda.Event(), torch.cuda.Event()
             main = torch.cuda.current_stream(self.grads.device)
             eng.forward_model(model.flat_parameters(), model.bn_state(), batch, eps,
