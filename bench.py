@@ -86,6 +86,7 @@ def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, 
     for s in range(steps):
         step_fn(batches[s % len(batches)], 0.25, 1.0)
         if iters_acc is not None:
+            step_fn.wait()                      # the iteration counts come from the side stream
             iters_acc += engine.iters_done.sum()
     torch.cuda.synchronize()
     if dist.is_initialized():
@@ -189,12 +190,15 @@ def main():
         if dist.is_initialized():
             dist.broadcast(model.flat_parameters(), src=0)
             note("parameters broadcast")
-        step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world, force_collectives=force_dist)
+        # as the trainer runs it: matching half on a second stream, steps pipelined
+        step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world, force_collectives=force_dist,
+                            pipeline=os.environ.get("GVAE_BENCH_PIPELINE", "1") == "1")
         eng = model._engine_for(batches[0])
         iters_acc = torch.zeros((), dtype=torch.int64, device=device)
         # W warm-up steps, then EXACTLY K timed steps (no instrumentation) -> `value`
         timed_steps(step_fn, batches, 0, args.warmup, world, device)
-        note("warm-up done")
+        note(f"warm-up done; side stream probe (candidates tried, found): "
+             f"{getattr(__import__('graphvae.train.train_ddp', fromlist=['x']).concurrent_stream, 'last_probe', None)}")
         dt = timed_steps(step_fn, batches, args.steps, 0, world, device)
         note(f"{args.steps} timed steps: {1e3 * dt / max(1, args.steps):.3f} ms per step")
         if leg == "stream":

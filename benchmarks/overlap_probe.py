@@ -1,8 +1,8 @@
 """Where the two streams of an overlapped step are at which time: HIP events on the main
 stream (after forward-model, backward, all-reduce, Adam) and on the side stream (after the
 matching half), printed as microseconds from the step's start (each step synchronised, so host launch
-latency shows; bench.py measures the free-running rate).  GVAE_SIDE_PRIORITY (default -1)
-sets the side stream's priority.  Run with
+latency shows; bench.py measures the free-running rate).  GVAE_SIDE_PRIORITY=p
+uses a stream of that priority instead of the probed one.  Run with
 GVAE_BENCH_FORCE_DIST=1 to include a one-rank RCCL all-reduce.
 usage: python benchmarks/overlap_probe.py [stream|fused] [steps=12]"""
 import os
@@ -34,7 +34,12 @@ model = model.to(dev).train()
 batches = [b.to(dev) for b in host]
 step = TrainStep(model, 1e-4, 1e-4, 5.0, force_collectives=force)
 eng = model._engine_for(batches[0])
-side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GVAE_SIDE_PRIORITY", "-1")))
+if "GVAE_SIDE_PRIORITY" in os.environ:
+    side = torch.cuda.Stream(device=dev, priority=int(os.environ["GVAE_SIDE_PRIORITY"]))
+else:
+    from graphvae.train.train_ddp import concurrent_stream
+    side = concurrent_stream(dev)
+    print("side stream probe (candidates tried, found):", concurrent_stream.last_probe)
 main = torch.cuda.current_stream(dev)
 names = ["fwd_model", "backward", "all_reduce", "adam", "match(side)", "joined"]
 acc = [0.0] * len(names)

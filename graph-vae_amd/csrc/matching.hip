@@ -1290,7 +1290,10 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   }
   // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
   // others leave, which only happens once every graph is finished, and then leave at once
-  const int max_blocks = 2048 * 256 / nt;
+  int max_blocks = 2048 * 256 / nt;
+#ifdef GVAE_TUNE
+  if (const char *e = getenv("GVAE_MPM_BLOCKS")) max_blocks = atoi(e);
+#endif
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
                      s_layout, d_iters_done);

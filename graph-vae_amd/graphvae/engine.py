@@ -111,9 +111,39 @@ def param_layout(F: int, H: int, Z: int, N: int):
     return list(off), list(size), int(tot)
 
 
+class _Slot:
+    """Everything one step in flight owns: workspace (activations, logits, X), permutations,
+    iteration counts, the four output scalars and the batch they belong to."""
+
+    def __init__(self, device) -> None:
+        self.ws = None
+        self.ws_graphs = 0
+        self.out4 = torch.zeros(4, dtype=torch.float32, device=device)
+        self.perm = None
+        self.iters_done = None
+        self.fwd_batch = None
+        self.pending = None
+
+
+def _slot_attr(name):
+    return property(lambda self: getattr(self._slots[self._cur], name),
+                    lambda self, v: setattr(self._slots[self._cur], name, v))
+
+
 class StepEngine:
     """Runs forward / backward / optimiser of one GraphVAE step for batches of up to any
-    size; scratch is grown on demand and reused."""
+    size; scratch is grown on demand and reused.  A caller that keeps two steps in flight
+    (the matching half of one step beside the model half of the next) alternates between two
+    slots with `use_slot`; `perm`, `iters_done`, `out4` and the workspace are those of the
+    current slot.  The similarity-tensor buffer is shared: matchings run one after the other."""
+
+    _ws = _slot_attr("ws")
+    _ws_graphs = _slot_attr("ws_graphs")
+    out4 = _slot_attr("out4")
+    perm = _slot_attr("perm")
+    iters_done = _slot_attr("iters_done")
+    _fwd_batch = _slot_attr("fwd_batch")
+    _pending = _slot_attr("pending")
 
     def __init__(self, F: int, H: int, Z: int, N: int, device, matching: str = "auto",
                  mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
@@ -128,8 +158,8 @@ class StepEngine:
             raise ValueError("matching must be auto | none | stream | fused")
         self.matching = matching
         self.mpm_iters, self.tol, self.early_stop = int(mpm_iters), float(tol), bool(early_stop)
-        self._ws = None
-        self._ws_graphs = 0
+        self._slots = [_Slot(self.device)]
+        self._cur = 0
         # the streamed matching keeps the similarity tensor of as many graphs as fit this many
         # bytes and walks the batch in chunks (default: a third of the device's memory)
         if s_budget_bytes is None:
@@ -140,13 +170,14 @@ class StepEngine:
         self._S_key = None
         self._S_chunks = None
         self._adam_ws = torch.empty(self.L.gvae_adam_ws_bytes(), dtype=torch.uint8, device=self.device)
-        self.out4 = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self.perm = None
-        self.iters_done = None
         self.generation = 0
-        self._fwd_batch = None
-        self._pending = None
         self.last_mode = MATCH_NONE
+
+    def use_slot(self, k: int) -> None:
+        """Makes slot k (created on first use) the one the following calls work on."""
+        while len(self._slots) <= k:
+            self._slots.append(_Slot(self.device))
+        self._cur = k
 
     # ------------------------------------------------------------------ helpers
     def _ensure(self, B: int) -> None:
@@ -298,15 +329,22 @@ class StepEngine:
             norm_out.data_ptr() if norm_out is not None else None, _hip._stream()))
 
     def check_matching(self) -> None:
-        """Synchronises and raises if the last forward's matching reported a fault (a negative
-        iteration count from the streamed MPM's work queue, or a non-finite assignment cost)."""
-        if self.iters_done is None:
-            return
-        if bool((self.iters_done < 0).any()):
-            raise _hip.GvaeHipError("streamed MPM: the device work queue faulted; X is invalid")
-        B = self.iters_done.shape[0]
-        if self.last_mode != MATCH_NONE and bool((self.debug_tensor("status", B) != 0).any()):
-            raise _hip.GvaeHipError("assignment: non-finite or infeasible cost matrix")
+        """Synchronises and raises if the last forward of any slot reported a fault in its
+        matching (a negative iteration count from the streamed MPM's work queue, or a
+        non-finite assignment cost)."""
+        cur = self._cur
+        try:
+            for k in range(len(self._slots)):
+                self._cur = k
+                if self.iters_done is None:
+                    continue
+                if bool((self.iters_done < 0).any()):
+                    raise _hip.GvaeHipError("streamed MPM: the device work queue faulted; X is invalid")
+                B = self.iters_done.shape[0]
+                if self.last_mode != MATCH_NONE and bool((self.debug_tensor("status", B) != 0).any()):
+                    raise _hip.GvaeHipError("assignment: non-finite or infeasible cost matrix")
+        finally:
+            self._cur = cur
 
     # ------------------------------------------------------------------ inspection (tests)
     _DEBUG = {"vec_logits": 0, "node_logits": 1, "P": 2, "X": 3, "mu": 4, "logvar_raw": 5, "rec_i": 6,

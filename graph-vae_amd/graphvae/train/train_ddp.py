@@ -133,13 +133,49 @@ def shard_indices(n: int, world: int, rank: int, shuffle: bool, epoch: int, seed
 
 
 # --------------------------------------------------------------------------- the step
+def concurrent_stream(device, tries: int = 4) -> "torch.cuda.Stream":
+    """A stream whose kernels run beside the current stream's.  HIP multiplexes a process's
+    streams over a few hardware queues (four by default) and packets of one queue execute in
+    order, so two streams that share a queue run one after the other however independent their
+    work is; which pool stream shares the current stream's queue depends on how many streams
+    other libraries (RCCL, c10d) took before.  Up to `tries` consecutive pool streams are
+    probed: about 2 ms of memory-bound kernels go to the current stream, a one-element kernel
+    to the candidate; the candidate is taken if its kernel ends while the others still run.
+    (A high-priority stream also gets a queue of its own, but cross-waits between priority
+    classes deadlocked intermittently under per-step host synchronisation: not used.)"""
+    main = torch.cuda.current_stream(device)
+    ballast = torch.empty(64 << 20, dtype=torch.float32, device=device)    # 256 MiB
+    flag = torch.zeros(1, device=device)
+    held = []                       # keeps rejected candidates alive so the pool moves on
+    chosen = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device)
+        held.append(cand)
+        torch.cuda.synchronize(device)
+        done_main, done_cand = torch.cuda.Event(), torch.cuda.Event()
+        for _k in range(20):
+            ballast.add_(1.0)
+        done_main.record(main)
+        with torch.cuda.stream(cand):
+            flag.add_(1.0)
+            done_cand.record(cand)
+        done_cand.synchronize()
+        if not done_main.query():   # the candidate finished while the ballast was running
+            chosen = cand
+            break
+    torch.cuda.synchronize(device)
+    concurrent_stream.last_probe = (len(held), chosen is not None)     # for logs
+    return chosen if chosen is not None else held[-1]
+
+
 class TrainStep:
     """forward + backward + gradient all-reduce + clip + Adam, all on flat buffers.
     loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
 
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
                  world: int = 1, group=None, sync_bn_buffers: bool = False, engine=None,
-                 force_collectives: bool = False, overlap_matching: bool = True) -> None:
+                 force_collectives: bool = False, overlap_matching: bool = True,
+                 pipeline: bool = False) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
         model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
         `sync_bn_buffers`: broadcast rank 0's BatchNorm running statistics before every forward,
@@ -154,7 +190,13 @@ class TrainStep:
         on the permutation (reference model.py:325-334 gathers prediction and ground truth
         through the same perm_full, so the edge loss visits each pair of real nodes exactly
         once), hence both halves only need the decoder's logits; they are joined before the
-        step returns.  Results are bit-identical to the sequential order."""
+        step returns.  Results are bit-identical to the sequential order.
+        `pipeline` (needs overlap_matching): the step returns WITHOUT that join, so the matching
+        half of step N also runs beside the model half, backward and Adam of step N+1 (two
+        workspaces alternate; a workspace is reused only after its matching has finished).
+        The returned loss tensor, `model.last_permutations()` and `loss_sum` are then valid on
+        the current stream only after `wait()`; parameters, gradients and optimiser state never
+        depend on the matching and are always in stream order."""
         self.model = model
         self._engine = engine
         self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
@@ -163,13 +205,41 @@ class TrainStep:
         self.collectives = world > 1 or force_collectives
         flat = model.flat_parameters()
         self.overlap_matching = bool(overlap_matching) and flat.is_cuda
+        self.pipeline = bool(pipeline) and self.overlap_matching
         self._side = None       # second stream + events, created on first use
         self._ev_model = self._ev_match = None
+        self._slot = 0
+        # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
+        # the losses are produced (on the side stream when the matching is overlapped)
+        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)
         self.grads = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.t = 0
+
+    def wait(self) -> None:
+        """Orders the current stream behind every matching half still in flight (a stream
+        wait, not a host synchronisation).  Needed before reading losses, permutations or
+        iteration counts of pipelined steps, and before a forward outside this object."""
+        if self._ev_match is not None:
+            main = torch.cuda.current_stream(self.grads.device)
+            for ev in self._ev_match:
+                if ev is not None:
+                    main.wait_event(ev)
+
+    def pop_loss_sum(self) -> torch.Tensor:
+        """Sum of rec + beta * kl over the steps since the last call (float64, device), then
+        reset; waits for the matching halves in flight."""
+        self.wait()
+        out = self.loss_sum.clone()
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.grads.device))
+            with torch.cuda.stream(self._side):
+                self.loss_sum.zero_()
+        else:
+            self.loss_sum.zero_()
+        return out
 
     def sync_buffers(self) -> None:
         """Every rank takes rank 0's BatchNorm running statistics."""
@@ -190,24 +260,33 @@ class TrainStep:
         overlap = self.overlap_matching and hasattr(eng, "forward_match_loss")
         if overlap:
             if self._side is None:
-                # high priority: the matching half is the step's critical path, and streams of
-                # another priority class never share a hardware queue with the current stream
-                # (with RCCL initialised, a default-priority stream created here ended up behind
-                # the current stream's packets and the two halves ran one after the other)
-                self._side = torch.cuda.Stream(device=self.grads.device, priority=-1)
-                self._ev_model, self._ev_match = torch.cuda.Event(), torch.cuda.Event()
+                self._side = concurrent_stream(self.grads.device)
+                self._ev_model = [torch.cuda.Event(), torch.cuda.Event()]
+                self._ev_match = [None, None]
             main = torch.cuda.current_stream(self.grads.device)
+            k = self._slot
+            if self.pipeline:
+                eng.use_slot(k)
+                if self._ev_match[k] is not None:
+                    # the matching that last used this workspace (two steps ago) is finished
+                    main.wait_event(self._ev_match[k])
             eng.forward_model(model.flat_parameters(), model.bn_state(), batch, eps,
                               model._pos_weight_dev(), True)
-            self._ev_model.record(main)
+            self._ev_model[k].record(main)
             with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ev_model)
+                self._side.wait_event(self._ev_model[k])
                 out4 = eng.forward_match_loss().clone()
-                self._ev_match.record(self._side)
+                self.loss_sum += (out4[0] + beta * out4[1]).double()
+                if self._ev_match[k] is None:
+                    self._ev_match[k] = torch.cuda.Event()
+                self._ev_match[k].record(self._side)
             out4.record_stream(main)
+            if self.pipeline:
+                self._slot ^= 1
         else:
             out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
                                model._pos_weight_dev(), True).clone()
+            self.loss_sum += (out4[0] + beta * out4[1]).double()
         eng.backward(model.flat_parameters(), model._pos_weight_dev(), self.grads, 1.0, beta)
         if self.collectives:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -215,10 +294,10 @@ class TrainStep:
         eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
                       self.lr * lr_scale, weight_decay=self.weight_decay, clip_max=self.clip_max,
                       grad_scale=1.0 / self.world, norm_out=self.grad_norm)
-        if overlap:
+        if overlap and not self.pipeline:
             # join: what follows on this stream (the caller reading the losses, the next forward
             # overwriting the workspace) is ordered behind the matching half
-            torch.cuda.current_stream(self.grads.device).wait_event(self._ev_match)
+            main.wait_event(self._ev_match[k])
         for bn in (model.bn1, model.bn2):
             bn.num_batches_tracked += batch.num_graphs
         return out4
@@ -318,7 +397,8 @@ def _ddp_worker(rank: int, world: int, args) -> None:
         dist.broadcast(model.bn_state(), src=0)
         dist.barrier()
 
-    step_fn = TrainStep(model, args.lr, args.weight_decay, args.clip_max, world)
+    step_fn = TrainStep(model, args.lr, args.weight_decay, args.clip_max, world,
+                        pipeline=not args.debug)
     tb, wb = _optional_loggers(args, rank)
     dbg = DebugState(tb, wb) if (args.debug and rank == 0) else _NoDbg()
 
@@ -334,8 +414,7 @@ def _ddp_worker(rank: int, world: int, args) -> None:
         for batch in dl_tr:
             frac = min(1.0, global_step / anneal_steps)
             beta = args.beta0 + (args.beta_final - args.beta0) * frac
-            out4 = step_fn(batch, beta, frac)
-            acc += (out4[0] + beta * out4[1]).double()      # stays on the device: no per-step sync
+            out4 = step_fn(batch, beta, frac)    # losses summed on the device: no per-step sync
             if args.debug and rank == 0:
                 o = out4.tolist()
                 dbg.log("train/rec", o[0])
@@ -348,9 +427,9 @@ def _ddp_worker(rank: int, world: int, args) -> None:
                     dbg.log("debug/grad_norm", step_fn.grad_norm.item())
             dbg.next()
             global_step += 1
+        tot_tr = step_fn.pop_loss_sum()                     # joins the matching halves in flight
         if getattr(model, "_engine", None) is not None:
             model._engine.check_matching()                  # once per epoch: faults of the matching kernels
-        tot_tr = acc.clone()
         if world > 1:
             dist.all_reduce(tot_tr, op=dist.ReduceOp.SUM)
         mean_tr = tot_tr.item() / max(1, len(dl_tr)) / world

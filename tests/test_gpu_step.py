@@ -150,27 +150,33 @@ def test_overlapped_matching_equals_sequential_step(matching):
     N, B = 32, 48
     host = [synthetic_batch("enzymes", B, N, "deg", seed=s) for s in (3, 4)]
     runs = []
-    for overlap in (False, True):
+    for overlap, pipeline in ((False, False), (True, False), (True, True)):
         torch.manual_seed(42)
         model = GraphVAE(1, 64, 32, N, matching=matching)
         model.precompute_dataset_rho(host)
         model = model.to(DEV).train()
-        step = TrainStep(model, 1e-2, 1e-4, 5.0, overlap_matching=overlap)
-        assert step.overlap_matching == overlap
+        step = TrainStep(model, 1e-2, 1e-4, 5.0, overlap_matching=overlap, pipeline=pipeline)
+        assert step.overlap_matching == overlap and step.pipeline == pipeline
         gen = torch.Generator(device="cpu").manual_seed(9)
         outs, perms, iters = [], [], []
-        for s in range(5):
+        for s in range(6):
             batch = host[s % 2].to(DEV)
             eps = torch.randn(B, 32, generator=gen).to(DEV)
-            outs.append(step(batch, 0.5, 1.0, eps=eps).cpu())
-            perms.append(model.last_permutations().cpu())
-            iters.append(model.last_mpm_iterations().cpu())
+            out4 = step(batch, 0.5, 1.0, eps=eps)
+            if s % 3 != 1:          # pipelined: some steps are left in flight behind the next one
+                step.wait()
+                outs.append(out4.cpu())
+                perms.append(model.last_permutations().cpu())
+                iters.append(model.last_mpm_iterations().cpu())
+        loss_sum = step.pop_loss_sum().cpu()
+        assert float(step.loss_sum) == 0.0
         model._engine.check_matching()
-        runs.append((torch.stack(outs), torch.stack(perms), torch.stack(iters),
+        runs.append((torch.stack(outs), torch.stack(perms), torch.stack(iters), loss_sum,
                      model.flat_parameters().detach().cpu().clone(), model.bn_state().cpu().clone()))
-    for a, b in zip(*runs):
-        assert torch.equal(a, b)
-    assert int(runs[0][2].min()) >= 1
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+    assert int(runs[0][2].min()) >= 1 and float(runs[0][3]) > 0.0
 
 
 @pytest.mark.parametrize("matching", ["fused", "stream"])
