@@ -151,3 +151,25 @@ def test_trainer_run_directory_is_loadable_by_the_sampler(tmp_path):
         edge_log, node_log, graphs = _sampler_decode(model, cfg, 4, device)
         assert edge_log.shape == (4, 36) and node_log.shape == (4, 9)
         assert all(torch.equal(a, a.T) for a in graphs)
+
+
+@pytest.mark.gpu
+def test_pipelined_trainer_equals_step_by_step_trainer(tmp_path, capfd):
+    """The trainer keeps two steps in flight (matching of one step beside the model half of the
+    next); with debug logging it reads the losses after every step and runs them one at a time.
+    Same seeds: the checkpoints must be bit-identical and the epoch losses printed the same."""
+    import re
+    from graphvae.train import train_ddp as T
+    outs = []
+    for name, debug in (("pipelined", False), ("stepwise", True)):
+        run = tmp_path / name
+        T.train({"trainer": {"dataset": "synthetic-enzymes", "feature_type": "deg", "epochs": 3,
+                             "batch_size": 16, "hid_dim": 16, "z_dim": 8, "max_nodes": 20,
+                             "log_dir": str(run), "no_wandb": True, "warm_epochs": 1, "debug": debug}})
+        text = capfd.readouterr().out
+        losses = re.findall(r"Ep (\d+) \| train ([-\d.naninf]+) \| val ([-\d.naninf]+)", text)
+        assert len(losses) == 3, text
+        outs.append((losses, torch.load(run / "graphvae_ddp.pt", weights_only=True)))
+    assert outs[0][0] == outs[1][0]
+    for k, v in outs[0][1].items():
+        assert torch.equal(v, outs[1][1][k]), k
