@@ -3,6 +3,7 @@
 // and the S-free fused MPM.  Compiled with -ffp-contract=off: every product and
 // sum below is a separately rounded fp32 operation, as on the reference's CPU path.
 #include "gvae_canonical.h"
+#include "gvae_lsap.h"
 #include "gvae_common.h"
 
 namespace gvae {
@@ -922,7 +923,8 @@ template <int NT, int KMAX>
 __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
-    int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done) {
+    int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done,
+    int64_t *__restrict__ perm, int n_perm, int32_t *__restrict__ status) {
   // control words at the front of the dynamic region (see mpm_stream_kernel): the 128-bit LDS
   // reads below need its base 16-byte aligned, which a static __shared__ object would undo
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -935,6 +937,10 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   const int R = Rarr[g];
   if (R <= 0) {
     if (tid == 0) iters_done[g] = 0;
+    if (perm) {
+      for (int k = tid; k < n_perm; k += nt) perm[(int64_t)g * n_perm + k] = k;
+      if (tid == 0) status[g] = 0;
+    }
     return;
   }
   const int R2 = R * R, W = (R + 31) >> 5, PS = R + 4;
@@ -1143,6 +1149,14 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     }
   }
   if (tid == 0) iters_done[g] = done;
+  // Epilogue (perm != nullptr): the assignment of this graph, by the first wavefront, straight
+  // from the X in LDS (row stride R, what the solver expects).  A graph that converges early
+  // starts its assignment early; as a separate launch the assignments start only after the
+  // slowest graph's last MPM iteration.
+  if (perm != nullptr) {
+    __syncthreads();               // the last iteration's Xs (iters == 0: the initial X)
+    if (tid < 64) lsap_wave(Xs, R, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
+  }
 }
 
 // after the persistent kernel: a queue fault (a bounded spin ran out) turns every graph's
@@ -1308,18 +1322,18 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   return check_launch("mpm_stream");
 }
 
-int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
-                   int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
-                   int64_t strideX, int iters, float tol, int early_stop, int32_t *d_iters_done,
-                   void *stream) {
-  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done, GVAE_EINVAL,
-               "mpm_fused: null pointer");
+static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                            int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                            int64_t strideX, int iters, float tol, int early_stop,
+                            int32_t *d_iters_done, int64_t *d_perm, int n_perm, int32_t *d_status,
+                            void *stream, const char *who) {
+  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done, GVAE_EINVAL, "%s: null pointer", who);
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
-               "mpm_fused: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", n_graphs, r_max, ld, ldx);
+               "%s: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", who, n_graphs, r_max, ld, ldx);
   const size_t lds = 4 * kCtlFloats + 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
                      4 * (size_t)r_max * ((r_max + 31) / 32);
   GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
-               "mpm_fused: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", r_max, lds);
+               "%s: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", who, r_max, lds);
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfileScope ps(F_MPM_FUSED, s);
@@ -1327,11 +1341,11 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_fused: cannot reserve %zu bytes of LDS: %s",
-                   lds, hipGetErrorString(e));
+      GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, lds,
+                   hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld, stride, d_X,
-                       ldx, strideX, iters, tol, early_stop, d_iters_done);
+                       ldx, strideX, iters, tol, early_stop, d_iters_done, d_perm, n_perm, d_status);
     return GVAE_OK;
   };
   int rc;
@@ -1339,7 +1353,27 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
   else if (r_max <= 64) rc = launch(mpm_fused_kernel<512, 8>, 512);
   else rc = launch(mpm_fused_kernel<1024, 16>, 1024);
   if (rc) return rc;
-  return check_launch("mpm_fused");
+  return check_launch(who);
+}
+
+int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                   int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                   int64_t strideX, int iters, float tol, int early_stop, int32_t *d_iters_done,
+                   void *stream) {
+  return mpm_fused_launch(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, d_X, ldx, strideX, iters,
+                          tol, early_stop, d_iters_done, nullptr, 0, nullptr, stream, "mpm_fused");
+}
+
+int gvae_mpm_fused_assign(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                          int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                          int64_t strideX, int iters, float tol, int early_stop,
+                          int32_t *d_iters_done, int64_t *d_perm, int n_perm, int32_t *d_status,
+                          void *stream) {
+  GVAE_REQUIRE(d_perm && d_status && n_perm >= r_max, GVAE_EINVAL,
+               "mpm_fused_assign: perm / status missing or n_perm=%d < r_max=%d", n_perm, r_max);
+  return mpm_fused_launch(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, d_X, ldx, strideX, iters,
+                          tol, early_stop, d_iters_done, d_perm, n_perm, d_status, stream,
+                          "mpm_fused_assign");
 }
 
 }  // extern "C"

@@ -371,11 +371,13 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
         TRY(gvae_mpm_stream(d_S, d_S_off + g0, GVAE_S_PADDED, d_R + g0, nb, r_max, w.X + g0 * NN, N,
                             NN, mpm_iters, tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
       }
+      TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
     } else {
-      TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
-                         mpm_iters, tol, early_stop, d_iters_done, s));
+      // S-free MPM with the assignment as its epilogue
+      TRY(gvae_mpm_fused_assign(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N,
+                                (int64_t)N * N, mpm_iters, tol, early_stop, d_iters_done, d_perm, N,
+                                w.status, s));
     }
-    TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
   }
   // losses (model.py:325-373)
   TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,

@@ -56,6 +56,9 @@ def lib() -> ctypes.CDLL:
                                      c_void_p, c_void_p]
         L.gvae_lsap.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p, c_int,
                                 c_void_p, c_void_p]
+        L.gvae_mpm_fused_assign.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_float,
+                                            c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         _lib = L
     return _lib
 
@@ -189,6 +192,25 @@ def mpm_fused(A, P, NS, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
                                 r_max, X.data_ptr(), X.shape[1], X.shape[1] * X.shape[2], iters, tol,
                                 int(early_stop), done.data_ptr(), _stream()))
     return done
+
+
+def mpm_fused_assign(A, P, NS, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
+                     early_stop: bool = True, n_perm: int | None = None):
+    """S-free MPM with the assignment as the kernel's epilogue: returns (iterations (G,) int32,
+    perm (G, n_perm) int64, status (G,) int32); X is updated in place."""
+    _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
+    _dev(X, torch.float32)
+    G, N, _ = A.shape
+    n_perm = N if n_perm is None else n_perm
+    done = torch.empty(G, dtype=torch.int32, device=X.device)
+    perm = torch.empty(G, n_perm, dtype=torch.int64, device=X.device)
+    status = torch.empty(G, dtype=torch.int32, device=X.device)
+    _check(lib().gvae_mpm_fused_assign(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N,
+                                       N * N, r_max, X.data_ptr(), X.shape[1],
+                                       X.shape[1] * X.shape[2], iters, tol, int(early_stop),
+                                       done.data_ptr(), perm.data_ptr(), n_perm, status.data_ptr(),
+                                       _stream()))
+    return done, perm, status
 
 
 def lsap(X, R, r_max: int, n_perm: int | None = None):

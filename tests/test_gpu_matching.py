@@ -47,6 +47,12 @@ def _run_all(hip, As, Ps, cfg, N=None, check_stream=True):
         Xf = hip.x0_uniform(Rh, N, dev)
         done_f = hip.mpm_fused(A, P, NS, R, max(Rh), Xf, iters, tol, es)
         out["X_fused"], out["done_fused"] = Xf.cpu().numpy(), done_f.cpu().numpy()
+        # the same MPM with the assignment as the kernel's epilogue: identical X, counts, perm
+        Xa = hip.x0_uniform(Rh, N, dev)
+        done_a, perm_a, status_a = hip.mpm_fused_assign(A, P, NS, R, max(Rh), Xa, iters, tol, es)
+        perm_f, status_f = hip.lsap(Xf, R, max(Rh))
+        assert torch.equal(Xa, Xf) and torch.equal(done_a, done_f)
+        assert torch.equal(perm_a, perm_f) and torch.equal(status_a, status_f)
     if check_stream:
         S, S_off = hip.edge_sim(A, P, NS, R, Rh)
         Xs = hip.x0_uniform(Rh, N, dev)
@@ -136,6 +142,38 @@ def test_lsap_flags_invalid_cost(hip):
     assert status.cpu().tolist() == [0, 1, 0]
     p2 = perm[2].cpu().numpy()
     assert sorted(p2[:5].tolist()) == list(range(5)) and p2[5:].tolist() == [5, 6, 7]
+
+
+def test_fused_assign_large_and_invalid_graphs(hip):
+    """Assignment epilogue of the S-free MPM on graphs of more than 64 nodes (two columns per
+    lane), a one-node graph, and a graph whose probabilities contain a NaN (status 1, identity)."""
+    rng = np.random.default_rng(5)
+    sizes = (70, 100, 115, 1, 33, 64, 65)
+    As, Ps = [], []
+    for R in sizes:
+        up = np.triu((rng.random((R, R)) < 0.2).astype(np.float32), 1)
+        As.append(up + up.T + np.eye(R, dtype=np.float32))
+        lg = np.triu(rng.normal(0, 1.5, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    o = _run_all(hip, As, Ps, (8, 1e-4, True), N=115, check_stream=False)
+    assert o["status"].tolist() == [0] * len(sizes)
+    for k, (A, P) in enumerate(zip(As, Ps)):
+        R = A.shape[0]
+        X, done = ora.mpm_sfree(A, P, iters=8)
+        assert o["done_fused"][k] == done and np.array_equal(o["X_fused"][k, :R, :R], X), R
+        assert np.array_equal(o["perm"][k, :R], ora.assign_perm(X)), R
+        assert np.array_equal(o["perm"][k, R:], np.arange(R, 115)), R
+    dev = torch.device("cuda:0")
+    A = torch.from_numpy(_pack(As[4:6], 64)).to(dev)
+    P = torch.from_numpy(_pack(Ps[4:6], 64)).to(dev)
+    P[0, 2, 3] = float("nan")
+    R = torch.tensor([33, 64], dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    X = hip.x0_uniform([33, 64], 64, dev)
+    _, perm, status = hip.mpm_fused_assign(A, P, NS, R, 64, X, 5, 1e-4, True)
+    assert status.cpu().tolist() == [1, 0]
+    assert perm[0].cpu().tolist() == list(range(64))
+    assert sorted(perm[1].cpu().tolist()) == list(range(64))
 
 
 def test_random_ragged_batch_vs_oracle(hip):
