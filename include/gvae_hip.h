@@ -115,11 +115,12 @@ int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const 
 int gvae_lsap(const float *d_X, int ldx, int64_t strideX, const int32_t *d_R, int n_graphs,
               int r_max, int64_t *d_perm, int n_perm, int32_t *d_status, void *stream);
 
-/* gvae_mpm_fused followed by gvae_lsap, in one launch (graphvae/models/model.py:317-323: the
- * MPM and the assignment on its result): the work-group that iterated a graph solves that
- * graph's assignment from the X it holds in LDS, so a graph that converges early is assigned
- * early instead of waiting for the slowest graph of the batch.  Same X, same perm, same status
- * as the two calls. */
+/* gvae_mpm_fused followed by gvae_lsap (graphvae/models/model.py:317-323: the MPM and the
+ * assignment on its result).  While every graph's work-group fits on the device at once (1024 /
+ * 512 / 256 graphs for r_max <= 32 / 64 / 115) this is ONE launch: the work-group that iterated
+ * a graph solves that graph's assignment from the X it holds in LDS, so a graph that converges
+ * early is assigned early instead of waiting for the slowest graph of the batch; larger batches
+ * run as the two launches.  Same X, same perm, same status either way. */
 int gvae_mpm_fused_assign(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                           int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
                           int64_t strideX, int iters, float tol, int early_stop,

@@ -176,6 +176,25 @@ def test_fused_assign_large_and_invalid_graphs(hip):
     assert sorted(perm[1].cpu().tolist()) == list(range(64))
 
 
+def test_fused_assign_beyond_resident_capacity(hip):
+    """More graphs than work-groups fit on the device at once: the call switches to two
+    launches; X, iteration counts, permutations and status must not change."""
+    rng = np.random.default_rng(11)
+    As, Ps = [], []
+    for k in range(1100):
+        R = int(rng.integers(2, 13))
+        up = np.triu((rng.random((R, R)) < 0.4).astype(np.float32), 1)
+        As.append(up + up.T + np.eye(R, dtype=np.float32))
+        lg = np.triu(rng.normal(0, 1.5, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    o = _run_all(hip, As, Ps, (50, 1e-4, True), N=12, check_stream=False)   # asserts the equality
+    for k in (0, 511, 1024, 1099):
+        R = As[k].shape[0]
+        X, done = ora.mpm_sfree(As[k], Ps[k])
+        assert o["done_fused"][k] == done and np.array_equal(o["X_fused"][k, :R, :R], X)
+        assert np.array_equal(o["perm"][k, :R], ora.assign_perm(X))
+
+
 def test_random_ragged_batch_vs_oracle(hip):
     """Seeded ragged batch (R from 2 to 40, incl. odd sizes): GPU == C oracle bit for bit."""
     rng = np.random.default_rng(99)
