@@ -1288,7 +1288,10 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   int nt = r_max >= 48 ? 1024 : 256;
   // measured on 256 graphs of 32 nodes with early stop: 2.77 ms at (1024, 4096) against 2.84 at
   // (256, 2048); grouping rows at all: 16-node graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512
-  q.low = 1024;
+  // With 1024-thread work-groups only 256 are resident (against 1280 of 256 threads), and
+  // cutting a row finer than there are work-groups to take the pieces only adds rounds of
+  // items: ENZYMES-shaped batch (64 graphs up to 126 nodes) 4.89 ms at 1024, 4.46 ms at 256.
+  q.low = nt == 1024 ? 256 : 1024;
   q.high = 4096;
 #ifdef GVAE_TUNE
   // tuning builds only: launch shape and item-shape thresholds from the environment
