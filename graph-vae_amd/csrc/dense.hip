@@ -53,16 +53,31 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc &d, int bx, int by, int
   // the operand's unit stride so that a wave's loads are contiguous
   const int am = a_kfast ? (tid >> 6) : (tid & 63), ak = a_kfast ? (tid & 63) : (tid >> 6);
   const int bn = b_nfast ? (tid & 63) : (tid >> 6), bk = b_nfast ? (tid >> 6) : (tid & 63);
+  // Addresses = uniform pointer (scalar registers: tile origin + r * uniform step) + ONE 32-bit
+  // byte offset per lane and operand (operands are far below 4 GiB; checked at launch).  With a
+  // 64-bit address per load the kernel needed 185 registers; at 128 four work-groups fit a CU
+  // and the kernel finds room beside one that leaves a quarter of the register file free.
+  const unsigned a_rs = (unsigned)d.a_rs * 4u, a_cs = (unsigned)d.a_cs * 4u;
+  const unsigned b_rs = (unsigned)d.b_rs * 4u, b_cs = (unsigned)d.b_cs * 4u;
+  const unsigned a_lane = (unsigned)(m0 + am) * a_rs + (unsigned)ak * a_cs;
+  const unsigned b_lane = (unsigned)bk * b_rs + (unsigned)(n0 + bn) * b_cs;
+  const unsigned a_step = 4u * (a_kfast ? a_rs : a_cs), b_step = 4u * (b_nfast ? b_rs : b_cs);
+  const char *Ab = reinterpret_cast<const char *>(A), *Bb = reinterpret_cast<const char *>(B);
   for (int k0 = k_begin; k0 < k_end; k0 += GT_K) {
     float ra[16], rb[16];
+    const char *Ak = Ab + (size_t)k0 * a_cs, *Bk = Bb + (size_t)k0 * b_rs;     // uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = a_kfast ? am + 4 * r : am, k = a_kfast ? ak : ak + 4 * r;
       const int gm = m0 + m, gk = k0 + k;
-      ra[r] = (gm < d.M && gk < k_end) ? A[gm * d.a_rs + gk * d.a_cs] : 0.0f;
+      ra[r] = (gm < d.M && gk < k_end)
+                  ? *reinterpret_cast<const float *>(Ak + (size_t)r * a_step + a_lane)
+                  : 0.0f;
       const int n = b_nfast ? bn : bn + 4 * r, kb = b_nfast ? bk + 4 * r : bk;
       const int gn = n0 + n, gkb = k0 + kb;
-      rb[r] = (gn < d.N && gkb < k_end) ? B[gkb * d.b_rs + gn * d.b_cs] : 0.0f;
+      rb[r] = (gn < d.N && gkb < k_end)
+                  ? *reinterpret_cast<const float *>(Bk + (size_t)r * b_step + b_lane)
+                  : 0.0f;
     }
     __syncthreads();  // previous tile's MFMA reads are done
 #pragma unroll
@@ -100,7 +115,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc &d, int bx, int by, int
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
+__global__ __launch_bounds__(256, 4) void gemm_kernel(GemmDesc d) {
   gemm_tile(d, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc d) {
 // surplus tiles leave at once.  The step's contractions are small (a few to a few dozen
 // tiles each), so members that do not depend on each other fill the chip together instead
 // of one after the other.
-__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup g) {
+__global__ __launch_bounds__(256, 4) void gemm_group_kernel(GemmGroup g) {
   int k = 0;
   while (k + 1 < g.n && (int)blockIdx.z >= g.z_begin[k + 1]) ++k;
   if ((int)blockIdx.x >= g.tiles_x[k] || (int)blockIdx.y >= g.tiles_y[k]) return;
@@ -137,9 +152,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(GemmGroup g) {
   if (d.splits > 1) splitk_reduce(d, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
+// the kernel addresses an operand as base + 32-bit byte offset (one batch member at a time)
+static bool operands_below_4gib(const GemmDesc &d) {
+  const int64_t a = ((int64_t)(d.M + GT_M) * d.a_rs + (int64_t)(d.K + GT_K) * d.a_cs) * 4;
+  const int64_t b = ((int64_t)(d.K + GT_K) * d.b_rs + (int64_t)(d.N + GT_N) * d.b_cs) * 4;
+  return d.a_rs >= 0 && d.a_cs >= 0 && d.b_rs >= 0 && d.b_cs >= 0 && a < (1LL << 32) && b < (1LL << 32);
+}
+
 int launch_gemm(const GemmDesc &d, hipStream_t s) {
   GVAE_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, GVAE_EINVAL,
                "gemm: bad descriptor (M=%d N=%d K=%d batch=%d)", d.M, d.N, d.K, d.batch);
+  GVAE_REQUIRE(operands_below_4gib(d), GVAE_ELIMIT, "gemm: operand of 4 GiB or more (M=%d N=%d K=%d)",
+               d.M, d.N, d.K);
   GVAE_REQUIRE(d.splits == 1 || (d.batch == 1 && d.splitk_ws), GVAE_EINVAL,
                "gemm: split-K needs batch == 1 and a workspace");
   dim3 grid(ceil_div(d.N, GT_N), ceil_div(d.M, GT_M), d.splits > 1 ? d.splits : d.batch);
@@ -184,6 +208,8 @@ int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk
     GVAE_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, GVAE_EINVAL,
                  "gemm group: bad descriptor %d (M=%d N=%d K=%d batch=%d)", k, d.M, d.N, d.K, d.batch);
     GVAE_REQUIRE(d.splits == 1 || d.batch == 1, GVAE_EINVAL, "gemm group: split-K needs batch == 1");
+    GVAE_REQUIRE(operands_below_4gib(d), GVAE_ELIMIT,
+                 "gemm group: operand of 4 GiB or more (M=%d N=%d K=%d)", d.M, d.N, d.K);
     g.d[k] = d;
     g.tiles_x[k] = ceil_div(d.N, GT_N);
     g.tiles_y[k] = ceil_div(d.M, GT_M);

@@ -1307,7 +1307,11 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   }
   // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
   // others leave, which only happens once every graph is finished, and then leave at once
-  int max_blocks = 2048 * 256 / nt;
+  // 256-thread launches: four work-groups per CU instead of the five that fit.  The fifth adds
+  // nothing to the streaming rate (measured), and the quarter of the register file it would
+  // take is what lets kernels of other streams (the backward's GEMMs, 128 registers) run beside
+  // this persistent kernel instead of queueing until it ends.
+  int max_blocks = nt == 256 ? 1024 : 2048 * 256 / nt;
 #ifdef GVAE_TUNE
   if (const char *e = getenv("GVAE_MPM_BLOCKS")) max_blocks = atoi(e);
 #endif
