@@ -345,14 +345,17 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
                               int matching, int mpm_iters, float tol, int early_stop, float *d_S,
                               const int64_t *d_S_off, const int32_t *h_chunk_begin, int n_chunks,
                               void *d_ws, float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
-                              hipStream_t s) {
+                              int phases, hipStream_t s) {
   const int B = n_graphs, Z = d->Z, N = d->N;
   const Workspace w = carve(d, B, (char *)d_ws);
+  const bool do_match = phases & GVAE_PHASE_MATCH, do_assign = phases & GVAE_PHASE_ASSIGN_LOSS;
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
-    hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
-    TRY(hipMemsetAsync(d_iters_done, 0, sizeof(int32_t) * B, s) == hipSuccess ? 0 : GVAE_ELAUNCH);
-  } else {
+    if (do_match) {
+      hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
+      TRY(hipMemsetAsync(d_iters_done, 0, sizeof(int32_t) * B, s) == hipSuccess ? 0 : GVAE_ELAUNCH);
+    }
+  } else if (do_match) {
     TRY(launch_prob(w.vec, w.node, B, N, w.P, s));
     TRY(gvae_node_sim(d_adj, w.P, d_R, B, N, (int64_t)N * N, w.NS, s));
     hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
@@ -371,14 +374,20 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
         TRY(gvae_mpm_stream(d_S, d_S_off + g0, GVAE_S_PADDED, d_R + g0, nb, r_max, w.X + g0 * NN, N,
                             NN, mpm_iters, tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
       }
-      TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
-    } else {
+    } else if (do_assign) {
       // S-free MPM with the assignment as its epilogue
       TRY(gvae_mpm_fused_assign(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N,
                                 (int64_t)N * N, mpm_iters, tol, early_stop, d_iters_done, d_perm, N,
                                 w.status, s));
+    } else {
+      TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
+                         mpm_iters, tol, early_stop, d_iters_done, s));
     }
   }
+  if (!do_assign) return 0;
+  // assignment (model.py:319-323), unless the S-free MPM above has already done it
+  if (matching == GVAE_MATCH_STREAM || (matching == GVAE_MATCH_FUSED && !do_match))
+    TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
   // losses (model.py:325-373)
   TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,
                       loss_variant == GVAE_LOSS_DUMMY_MASKED, w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
@@ -424,7 +433,7 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
   TRY(forward_model(d, d_params, d_bn_state, d_x, d_adj, d_n_x, d_R, n_graphs, d_eps, train, d_ws, s));
   TRY(forward_match_loss(d, d_adj, d_R, n_graphs, r_max, d_pos_weight, loss_variant, matching,
                          mpm_iters, tol, early_stop, d_S, d_S_off, h_chunk_begin, n_chunks, d_ws,
-                         d_out4, d_perm, d_iters_done, s));
+                         d_out4, d_perm, d_iters_done, GVAE_PHASE_MATCH | GVAE_PHASE_ASSIGN_LOSS, s));
   return check_launch("step_forward");
 }
 
@@ -447,14 +456,16 @@ int gvae_step_forward_match_loss(const gvae_dims *d, const float *d_adj, const i
                                  int early_stop, float *d_S, const int64_t *d_S_off,
                                  const int32_t *h_chunk_begin, int n_chunks, void *d_ws,
                                  float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
-                                 void *stream) {
+                                 int phases, void *stream) {
   GVAE_REQUIRE(d && d_adj && d_R && d_pos_weight && d_ws && d_out4 && d_perm && d_iters_done,
                GVAE_EINVAL, "step_forward_match_loss: null pointer");
+  GVAE_REQUIRE(phases >= 1 && phases <= (GVAE_PHASE_MATCH | GVAE_PHASE_ASSIGN_LOSS), GVAE_EINVAL,
+               "step_forward_match_loss: phases=%d", phases);
   TRY(check_match_args(d, n_graphs, r_max, loss_variant, matching, d_S, d_S_off, h_chunk_begin,
                        n_chunks, "step_forward_match_loss"));
   TRY(forward_match_loss(d, d_adj, d_R, n_graphs, r_max, d_pos_weight, loss_variant, matching,
                          mpm_iters, tol, early_stop, d_S, d_S_off, h_chunk_begin, n_chunks, d_ws,
-                         d_out4, d_perm, d_iters_done, (hipStream_t)stream));
+                         d_out4, d_perm, d_iters_done, phases, (hipStream_t)stream));
   return check_launch("step_forward_match_loss");
 }
 

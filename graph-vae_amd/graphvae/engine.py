@@ -17,6 +17,7 @@ P_COUNT = 20
 MATCH_NONE, MATCH_STREAM, MATCH_FUSED = 0, 1, 2
 _MATCH = {"none": MATCH_NONE, "stream": MATCH_STREAM, "fused": MATCH_FUSED}
 LOSS_CURRENT, LOSS_DUMMY_MASKED = 0, 1   # GVAE_LOSS_* of the library
+PHASE_MATCH, PHASE_ASSIGN_LOSS = 1, 2    # GVAE_PHASE_* of the library
 
 # parameter tensors in flat-buffer order (reference module named_parameters() order)
 PARAM_NAMES = [
@@ -57,7 +58,7 @@ def _bind():
     L.gvae_step_forward_match_loss.argtypes = [POINTER(Dims), c_void_p, c_void_p, c_int, c_int,
                                                c_void_p, c_int, c_int, c_int, c_float, c_int,
                                                c_void_p, c_void_p, POINTER(c_int32), c_int, c_void_p,
-                                               c_void_p, c_void_p, c_void_p, c_void_p]
+                                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     L.gvae_step_read_debug.argtypes = [POINTER(Dims), c_int, c_void_p, c_int, POINTER(c_void_p),
                                        POINTER(c_int64)]
     L.gvae_adam_ws_bytes.restype = c_int64
@@ -274,26 +275,38 @@ class StepEngine:
             eps.data_ptr(), int(train), self._ws.data_ptr(), _hip._stream()))
         self.generation += 1
         self._fwd_batch = (batch, eps, int(loss_variant))
-        self._pending = (B, r_max, mode, pos_weight)
+        self._pending = (B, r_max, mode, pos_weight, PHASE_MATCH | PHASE_ASSIGN_LOSS)
         self.last_mode = mode
 
-    def forward_match_loss(self) -> torch.Tensor:
+    def forward_match_loss(self, phases: int = PHASE_MATCH | PHASE_ASSIGN_LOSS) -> torch.Tensor:
         """Second half of `forward` (matching, assignment, losses) for the batch of the last
-        `forward_model`, enqueued on the CURRENT stream; returns the device tensor
-        [rec, kl, max_logit, logvar_max] (engine memory).  The parameter gradients do not
-        depend on the permutation (reference model.py:325-334 gathers prediction and truth
-        through the same permutation), so this may run concurrently with `backward`."""
-        if getattr(self, "_pending", None) is None:
+        `forward_model` on this slot, enqueued on the CURRENT stream; returns the device tensor
+        [rec, kl, max_logit, logvar_max] (engine memory, valid once PHASE_ASSIGN_LOSS has run).
+        The parameter gradients do not depend on the permutation (reference model.py:325-334
+        gathers prediction and truth through the same permutation), so this may run concurrently
+        with `backward`.  `phases`: PHASE_MATCH (similarity tensor + MPM) and PHASE_ASSIGN_LOSS
+        (assignment + losses) may be enqueued by two calls, the second ordered behind the first
+        (possibly on another stream)."""
+        if self._pending is None:
             raise _hip.GvaeHipError("forward_match_loss called without a forward_model before it")
-        B, r_max, mode, pos_weight = self._pending
+        B, r_max, mode, pos_weight, todo = self._pending
+        if phases & ~todo or not phases:
+            raise _hip.GvaeHipError(f"forward_match_loss: phases {phases} not outstanding ({todo})")
+        if (phases & PHASE_ASSIGN_LOSS) and (todo & PHASE_MATCH) and not (phases & PHASE_MATCH):
+            raise _hip.GvaeHipError("forward_match_loss: assignment requested before the matching")
         batch, _eps, loss_variant = self._fwd_batch
-        self._pending = None
-        S_ptr, Soff_ptr, chunks, n_chunks = self._S_args(mode, batch)
+        todo &= ~phases
+        self._pending = (B, r_max, mode, pos_weight, todo) if todo else None
+        S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch) if phases & PHASE_MATCH
+                                             else (None, None, None, 0))
+        if mode == MATCH_STREAM and not (phases & PHASE_MATCH):
+            S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()    # validated, unused
         _hip._check(self.L.gvae_step_forward_match_loss(
             ctypes.byref(self.dims), batch.adj_dense.data_ptr(), batch.num_real_nodes.data_ptr(), B,
             r_max, pos_weight.data_ptr(), loss_variant, mode, self.mpm_iters, self.tol,
             int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
-            self.out4.data_ptr(), self.perm.data_ptr(), self.iters_done.data_ptr(), _hip._stream()))
+            self.out4.data_ptr(), self.perm.data_ptr(), self.iters_done.data_ptr(), int(phases),
+            _hip._stream()))
         return self.out4
 
     def backward(self, params: torch.Tensor, pos_weight: torch.Tensor, grads: torch.Tensor,

@@ -35,6 +35,7 @@ import yaml
 
 from ..data import (DenseGraphBatch, DenseLoader, GraphData, collate, graph_from_adjacency,
                     graph_from_networkx, synthetic_adjacencies)
+from ..engine import PHASE_ASSIGN_LOSS, PHASE_MATCH
 from ..models.model import GraphVAE
 
 SEED = 42
@@ -133,17 +134,18 @@ def shard_indices(n: int, world: int, rank: int, shuffle: bool, epoch: int, seed
 
 
 # --------------------------------------------------------------------------- the step
-def concurrent_stream(device, tries: int = 4) -> "torch.cuda.Stream":
-    """A stream whose kernels run beside the current stream's.  HIP multiplexes a process's
-    streams over a few hardware queues (four by default) and packets of one queue execute in
-    order, so two streams that share a queue run one after the other however independent their
-    work is; which pool stream shares the current stream's queue depends on how many streams
-    other libraries (RCCL, c10d) took before.  Up to `tries` consecutive pool streams are
-    probed: about 2 ms of memory-bound kernels go to the current stream, a one-element kernel
-    to the candidate; the candidate is taken if its kernel ends while the others still run.
-    (A high-priority stream also gets a queue of its own, but cross-waits between priority
-    classes deadlocked intermittently under per-step host synchronisation: not used.)"""
-    main = torch.cuda.current_stream(device)
+def concurrent_stream(device, others=(), tries: int = 4) -> "torch.cuda.Stream":
+    """A stream whose kernels run beside the current stream's (and beside those of `others`).
+    HIP multiplexes a process's streams over a few hardware queues (four by default) and
+    packets of one queue execute in order, so two streams that share a queue run one after the
+    other however independent their work is; which pool stream shares a queue with which
+    depends on how many streams other libraries (RCCL, c10d) took before.  Up to `tries`
+    consecutive pool streams are probed: about 2 ms of memory-bound kernels go to a reference
+    stream, a one-element kernel to the candidate; the candidate passes if its kernel ends
+    while the others still run.  (A high-priority stream also gets a queue of its own, but
+    cross-waits between priority classes deadlocked intermittently under per-step host
+    synchronisation: not used.)"""
+    refs = [torch.cuda.current_stream(device)] + list(others)
     ballast = torch.empty(64 << 20, dtype=torch.float32, device=device)    # 256 MiB
     flag = torch.zeros(1, device=device)
     held = []                       # keeps rejected candidates alive so the pool moves on
@@ -151,16 +153,22 @@ def concurrent_stream(device, tries: int = 4) -> "torch.cuda.Stream":
     for _ in range(tries):
         cand = torch.cuda.Stream(device=device)
         held.append(cand)
-        torch.cuda.synchronize(device)
-        done_main, done_cand = torch.cuda.Event(), torch.cuda.Event()
-        for _k in range(20):
-            ballast.add_(1.0)
-        done_main.record(main)
-        with torch.cuda.stream(cand):
-            flag.add_(1.0)
-            done_cand.record(cand)
-        done_cand.synchronize()
-        if not done_main.query():   # the candidate finished while the ballast was running
+        ok = True
+        for ref in refs:
+            torch.cuda.synchronize(device)
+            done_ref, done_cand = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(ref):
+                for _k in range(20):
+                    ballast.add_(1.0)
+                done_ref.record(ref)
+            with torch.cuda.stream(cand):
+                flag.add_(1.0)
+                done_cand.record(cand)
+            done_cand.synchronize()
+            if done_ref.query():    # the candidate only ran once the ballast was through
+                ok = False
+                break
+        if ok:
             chosen = cand
             break
     torch.cuda.synchronize(device)
@@ -207,7 +215,8 @@ class TrainStep:
         self.overlap_matching = bool(overlap_matching) and flat.is_cuda
         self.pipeline = bool(pipeline) and self.overlap_matching
         self._side = None       # second stream + events, created on first use
-        self._ev_model = self._ev_match = None
+        self._tail = None       # pipelined: third stream for assignment + losses
+        self._ev_model = self._ev_match = self._ev_mpm = None
         self._slot = 0
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
@@ -234,8 +243,9 @@ class TrainStep:
         self.wait()
         out = self.loss_sum.clone()
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(self.grads.device))
-            with torch.cuda.stream(self._side):
+            acc_stream = self._tail if self._tail is not None else self._side
+            acc_stream.wait_stream(torch.cuda.current_stream(self.grads.device))
+            with torch.cuda.stream(acc_stream):
                 self.loss_sum.zero_()
         else:
             self.loss_sum.zero_()
@@ -262,7 +272,12 @@ class TrainStep:
             if self._side is None:
                 self._side = concurrent_stream(self.grads.device)
                 self._ev_model = [torch.cuda.Event(), torch.cuda.Event()]
+                self._ev_mpm = [torch.cuda.Event(), torch.cuda.Event()]
                 self._ev_match = [None, None]
+                if self.pipeline:
+                    # assignment + losses of step N (one wavefront per graph, latency-bound) run
+                    # beside the similarity tensor and the MPM of step N+1
+                    self._tail = concurrent_stream(self.grads.device, others=[self._side])
             main = torch.cuda.current_stream(self.grads.device)
             k = self._slot
             if self.pipeline:
@@ -273,13 +288,25 @@ class TrainStep:
             eng.forward_model(model.flat_parameters(), model.bn_state(), batch, eps,
                               model._pos_weight_dev(), True)
             self._ev_model[k].record(main)
+            last = self._side
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._ev_model[k])
-                out4 = eng.forward_match_loss().clone()
+                if self._tail is None:
+                    out4 = eng.forward_match_loss()
+                else:
+                    eng.forward_match_loss(PHASE_MATCH)
+                    self._ev_mpm[k].record(self._side)
+            if self._tail is not None:
+                last = self._tail
+                with torch.cuda.stream(self._tail):
+                    self._tail.wait_event(self._ev_mpm[k])
+                    out4 = eng.forward_match_loss(PHASE_ASSIGN_LOSS)
+            with torch.cuda.stream(last):
+                out4 = out4.clone()
                 self.loss_sum += (out4[0] + beta * out4[1]).double()
                 if self._ev_match[k] is None:
                     self._ev_match[k] = torch.cuda.Event()
-                self._ev_match[k].record(self._side)
+                self._ev_match[k].record(last)
             out4.record_stream(main)
             if self.pipeline:
                 self._slot ^= 1

@@ -210,7 +210,12 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
  * concurrently with gvae_step_backward of the same batch: it reads the logits, mu and logvar
  * and writes only buffers the backward never touches.  The caller joins the two streams
  * before it reads d_out4 / d_perm and before the next forward reuses the workspace.
- * Arguments as in gvae_step_forward. */
+ * Arguments as in gvae_step_forward.  `phases` selects what the call enqueues: GVAE_PHASE_MATCH
+ * (similarity tensor and MPM), GVAE_PHASE_ASSIGN_LOSS (assignment, losses, diagnostics; after
+ * the matching of the same batch) or both; a caller with a third stream lets the assignment
+ * of one batch (one wavefront per graph, latency-bound) run beside the matching of the next. */
+#define GVAE_PHASE_MATCH 1
+#define GVAE_PHASE_ASSIGN_LOSS 2
 int gvae_step_forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,
                             const float *d_x, const float *d_adj, const int32_t *d_n_x,
                             const int32_t *d_R, int n_graphs, const float *d_eps, int train,
@@ -221,7 +226,7 @@ int gvae_step_forward_match_loss(const gvae_dims *d, const float *d_adj, const i
                                  int early_stop, float *d_S, const int64_t *d_S_off,
                                  const int32_t *h_chunk_begin, int n_chunks, void *d_ws,
                                  float *d_out4, int64_t *d_perm, int32_t *d_iters_done,
-                                 void *stream);
+                                 int phases, void *stream);
 
 /* Backward of  c_rec*up[0]*rec + c_kl*up[1]*kl  with respect to every parameter
  * (what loss.backward() does in graphvae/train/train_ddp.py:283-291, where
