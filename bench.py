@@ -8,15 +8,19 @@ full optimisation step on one batch of synthetic graphs already resident in HBM:
 heads, decoder, matching (similarity tensor + MPM), assignment, losses, backward, gradient
 all-reduce (RCCL), clipping and Adam.  Rank 0 prints ONE JSON line.
 
-Workloads (BASELINE.json configs; per-GPU batch is fixed, so scaling is weak):
-  c2  dense graphs, max_nodes 32, batch 256                 (default; matching-dominated)
+Workloads (BASELINE.json configs).  c2 keeps the per-GPU batch fixed ("scaling": "weak"); the
+others divide their global batch over the ranks ("strong"):
+  c2  dense graphs, max_nodes 32, batch 256 per GPU         (default; matching-dominated)
   c3  ENZYMES-shaped graphs padded to 126, batch 64 over all ranks
   c4  dense graphs, max_nodes 64, batch 1024 over all ranks, fixed MPM iterations (--mpm-iters)
   c5  dense graphs, max_nodes 128, batch 512 over all ranks
 The default matching path is "stream": the reference's algorithm with the (R,R,R,R)
 similarity tensor materialised in HBM and streamed once per MPM iteration; that is the
 kernel the HBM roofline figure refers to.  The S-free fused path gives identical bits and is
-timed as well (reported under "fused").
+timed as well (reported under "fused").  Steps run as the trainer runs them: matching on a
+second stream beside backward + Adam, assignment + losses on a third, two steps in flight
+(GVAE_BENCH_PIPELINE=0: one step at a time); the timed region ends with a device-wide
+synchronisation, so every stream's work of the K steps is inside it.
 """
 from __future__ import annotations
 
@@ -253,7 +257,7 @@ def main():
     line = {
         "metric": "training graphs/sec", "value": main_leg["value"], "unit": "graphs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak" if global_batch is None else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic {kind} graphs, max_nodes={N}, "
                                f"batch {main_leg['per_gpu_batch']} per GPU, deg features, hid 128, z 64, "
