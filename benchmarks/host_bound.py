@@ -26,3 +26,22 @@ for matching in ("fused", "stream"):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"{matching}: host enqueue {1e3*(t1-t0)/n:.3f} ms per step, total {1e3*(t2-t0)/n:.3f} ms per step")
+
+# where the host time of a streamed step goes: wall time inside each engine call
+import collections
+acc = collections.defaultdict(float)
+eng = model._engine
+for name in ("forward_model", "forward_match_loss", "backward", "adam_step"):
+    fn = getattr(eng, name)
+
+    def timed(*a, _fn=fn, _name=name, **k):
+        t = time.perf_counter()
+        r = _fn(*a, **k)
+        acc[_name + (str(a[0]) if _name == "forward_match_loss" and a else "")] += time.perf_counter() - t
+        return r
+    setattr(eng, name, timed)
+n = 100
+for s in range(n):
+    step(batches[s % 2], 0.25, 1.0)
+torch.cuda.synchronize()
+print("stream, host ms per step inside:", {k: round(1e3 * v / n, 3) for k, v in acc.items()})

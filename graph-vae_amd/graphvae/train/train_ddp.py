@@ -288,28 +288,35 @@ class TrainStep:
             eng.forward_model(model.flat_parameters(), model.bn_state(), batch, eps,
                               model._pos_weight_dev(), True)
             self._ev_model[k].record(main)
-            last = self._side
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ev_model[k])
-                if self._tail is None:
-                    out4 = eng.forward_match_loss()
-                else:
-                    eng.forward_match_loss(PHASE_MATCH)
-                    self._ev_mpm[k].record(self._side)
-            if self._tail is not None:
-                last = self._tail
-                with torch.cuda.stream(self._tail):
-                    self._tail.wait_event(self._ev_mpm[k])
-                    out4 = eng.forward_match_loss(PHASE_ASSIGN_LOSS)
-            with torch.cuda.stream(last):
-                out4 = out4.clone()
-                self.loss_sum += (out4[0] + beta * out4[1]).double()
-                if self._ev_match[k] is None:
-                    self._ev_match[k] = torch.cuda.Event()
-                self._ev_match[k].record(last)
-            out4.record_stream(main)
-            if self.pipeline:
-                self._slot ^= 1
+
+            def enqueue_matching():
+                last = self._side
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(self._ev_model[k])
+                    if self._tail is None:
+                        out = eng.forward_match_loss()
+                    else:
+                        eng.forward_match_loss(PHASE_MATCH)
+                        self._ev_mpm[k].record(self._side)
+                if self._tail is not None:
+                    last = self._tail
+                    with torch.cuda.stream(self._tail):
+                        self._tail.wait_event(self._ev_mpm[k])
+                        out = eng.forward_match_loss(PHASE_ASSIGN_LOSS)
+                with torch.cuda.stream(last):
+                    out = out.clone()
+                    self.loss_sum += (out[0] + beta * out[1]).double()
+                    if self._ev_match[k] is None:
+                        self._ev_match[k] = torch.cuda.Event()
+                    self._ev_match[k].record(last)
+                out.record_stream(main)
+                return out
+
+            # pipelined: the main chain is enqueued first (the runtime makes the host wait once a
+            # stream holds more than a few dozen unfinished commands, which the side streams do
+            # while the previous MPM runs; that wait must not hold back the backward)
+            if not self.pipeline:
+                out4 = enqueue_matching()
         else:
             out4 = eng.forward(model.flat_parameters(), model.bn_state(), batch, eps,
                                model._pos_weight_dev(), True).clone()
@@ -321,6 +328,9 @@ class TrainStep:
         eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
                       self.lr * lr_scale, weight_decay=self.weight_decay, clip_max=self.clip_max,
                       grad_scale=1.0 / self.world, norm_out=self.grad_norm)
+        if overlap and self.pipeline:
+            out4 = enqueue_matching()
+            self._slot ^= 1
         if overlap and not self.pipeline:
             # join: what follows on this stream (the caller reading the losses, the next forward
             # overwriting the workspace) is ordered behind the matching half
