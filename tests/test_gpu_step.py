@@ -179,6 +179,33 @@ def test_overlapped_matching_equals_sequential_step(matching):
     assert int(runs[0][2].min()) >= 1 and float(runs[0][3]) > 0.0
 
 
+def test_split_forward_phase_order_is_enforced(golden_dir):
+    """The match/loss half in separate calls: the assignment cannot be requested before the
+    matching, no phase twice, nothing without a model half; done in order it equals `forward`."""
+    from graphvae import _hip
+    from graphvae.engine import PHASE_ASSIGN_LOSS, PHASE_MATCH
+    G = load_g5(golden_dir / "g5_forward_rand_deg.npz")
+    model, batch, eps = _model_and_batch(G, "stream")
+    model.train()
+    eng = model._engine_for(batch)
+    args = (model.flat_parameters(), model.bn_state().clone(), batch, eps, model._pos_weight_dev(), True)
+    with pytest.raises(_hip.GvaeHipError):
+        eng.forward_match_loss()
+    ref = eng.forward(*args).clone()
+    perm_ref = eng.perm.clone()
+    args = (model.flat_parameters(), model.bn_state().clone(), batch, eps, model._pos_weight_dev(), True)
+    eng.forward_model(*args)
+    with pytest.raises(_hip.GvaeHipError):
+        eng.forward_match_loss(PHASE_ASSIGN_LOSS)
+    eng.forward_match_loss(PHASE_MATCH)
+    with pytest.raises(_hip.GvaeHipError):
+        eng.forward_match_loss(PHASE_MATCH)
+    out = eng.forward_match_loss(PHASE_ASSIGN_LOSS).clone()
+    with pytest.raises(_hip.GvaeHipError):
+        eng.forward_match_loss(PHASE_ASSIGN_LOSS)
+    assert torch.equal(out, ref) and torch.equal(eng.perm, perm_ref)
+
+
 @pytest.mark.parametrize("matching", ["fused", "stream"])
 def test_forward_old_vs_reference_golden(golden_dir, matching):
     """The legacy loss (reference model.py:378-440) on a batch with padded nodes: losses,
