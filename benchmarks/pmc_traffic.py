@@ -3,6 +3,7 @@ collected in separate runs) -> an entry of profiles/pmc_traffic.json and rows of
 
 usage: python benchmarks/pmc_traffic.py <key> <fetch dir> <write dir> <kernel substring>
                                         <nodes R> <executed graph-iterations> <command text>
+                                        [algorithmic bytes of the launch, for ragged batches]
 
 gfx950 correction: on wide coalesced streams FETCH_SIZE counts 64 B per 128-B request, so it
 is doubled; WRITE_SIZE is taken as read; both are in KiB."""
@@ -30,7 +31,7 @@ def mean_for(d, counter):
 fetch_kb, n_f = mean_for(d_fetch, "FETCH_SIZE")
 write_kb, n_w = mean_for(d_write, "WRITE_SIZE")
 hbm = 2.0 * fetch_kb * 1024 + write_kb * 1024
-alg = gi * (4 * R ** 4 + 12 * R ** 2)
+alg = float(sys.argv[8]) if len(sys.argv) > 8 else gi * (4 * R ** 4 + 12 * R ** 2)
 entry = {
     "kernel": sub, "command": cmd, "launches_averaged": [n_f, n_w],
     "fetch_size_kb_mean": fetch_kb, "write_size_kb_mean": write_kb, "graph_iterations": gi,
