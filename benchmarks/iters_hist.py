@@ -1,3 +1,6 @@
+"""Histogram of the MPM iterations per graph on the bench's c2 batches (early stop at 1e-4, at most
+50): how many graphs run to the cap and how long the under-filled tail of the streamed MPM is.
+usage: python benchmarks/iters_hist.py"""
 import sys, torch, numpy as np
 sys.path.insert(0, "graph-vae_amd")
 from graphvae.data import synthetic_batch
