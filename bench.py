@@ -215,17 +215,22 @@ def main():
             ms_iter, n_iter = _hip.profile_read("mpm_stream_iter")
             ms_es, n_es = _hip.profile_read("edge_sim")
             _hip.profile_reset()
-            # algorithmic bytes of the streaming MPM kernel: every executed (graph, iteration)
-            # reads S once (4 R^4) plus X, X_new and the node block (12 R^2)
+            # algorithmic bytes of the streaming MPM kernel: every (graph, iteration) it executes
+            # reads S once (4 R^4) plus X, X_new and the node block (12 R^2).  The first iteration
+            # of a graph is not among them: the step computes it from row maxima of S without
+            # reading the tensor back (gvae_match_stream), so the kernel streams iterations 2..k.
             r = np.array([rr for s in range(args.steps) for rr in batches[s % len(batches)].r_host],
                          dtype=np.float64)
+            first = 1.0 if args.mpm_iters >= 1 else 0.0
             if early_stop:
                 # iterations differ per graph: use the device-side total and the batch's mean
                 # bytes per graph-iteration (exact for uniform-size workloads)
                 bytes_per_gi = float(np.mean(4.0 * r ** 4 + 12.0 * r ** 2))
-                alg_bytes = float(iters_acc.item()) * bytes_per_gi
+                streamed_gi = float(iters_acc.item()) - first * len(r)
+                alg_bytes = streamed_gi * bytes_per_gi
             else:
-                alg_bytes = float(np.sum(4.0 * r ** 4 + 12.0 * r ** 2)) * args.mpm_iters
+                streamed_gi = float(len(r)) * (args.mpm_iters - first)
+                alg_bytes = float(np.sum(4.0 * r ** 4 + 12.0 * r ** 2)) * (args.mpm_iters - first)
             achieved = alg_bytes / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else 0.0
             # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as gfx950 needs,
             # + WRITE_SIZE), measured with rocprofv3 on this workload's kernel and stored per
@@ -235,8 +240,7 @@ def main():
             try:
                 pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(args.workload)
                 if pmc:
-                    gi = float(iters_acc.item()) if early_stop else float(len(r)) * args.mpm_iters
-                    traffic = pmc["hbm_bytes_per_graph_iteration"] * gi / max(1, n_iter)
+                    traffic = pmc["hbm_bytes_per_graph_iteration"] * streamed_gi / max(1, n_iter)
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except OSError:
                 pass

@@ -792,7 +792,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
 __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
                                                               const int32_t *__restrict__ Rarr,
                                                               int n_graphs, int r_max, int layout,
-                                                              int32_t *__restrict__ iters_done) {
+                                                              int32_t *__restrict__ iters_done,
+                                                              const int32_t *__restrict__ first_stop,
+                                                              int iters) {
+  // first_stop != nullptr: the first iteration has been done already (mpm_first_iter_kernel):
+  // iters_done holds 1, and a graph that converged in it, or whose budget is one iteration,
+  // gets no items
   __shared__ int s_part[1024];
   __shared__ int s_live[1024];
   const int tid = threadIdx.x;
@@ -802,6 +807,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     const int R = Rarr[g];
     if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
     if (R <= 0 || R > r_max) { shape = 0; return 0; }
+    if (first_stop && (first_stop[g] != 0 || iters <= 1)) { shape = 0; return 0; }
     shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high);
     return mpm_shape_items(R, shape);
   };
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     mine += n;
     live += n > 0;
     q.arrive[g] = 0;
-    iters_done[g] = 0;
+    if (!first_stop) iters_done[g] = 0;
   }
   s_part[tid] = mine;
   s_live[tid] = live;
@@ -840,6 +846,99 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// First MPM iteration of the streamed matching, without reading S.  X0 is uniform
+// (x0 = 1/R, reference model.py:317), so for every row (j,a) of the slab of i
+//   T[j,a] = max_b fl(S[i,j,a,b] * x0) = fl((max_b S[i,j,a,b]) * x0)        (rounding is monotone)
+// and the row maximum needs no tensor: for j != i the row holds fl(A[i,j]*P[a,b]) for b != a and
+// a zero at b == a, hence
+//   max_b S[i,j,a,b] = max(0, fl(A[i,j] * pmax[a])),   pmax[a] = max_{b != a} P[a,b]
+// (pmin[a] in place of pmax[a] when A[i,j] < 0).  The rest is the iteration as the streaming
+// kernel does it: Xn[i,a] = fl(x0 * NS[i,a]) + canonical column sum of T over j (j == i: +0),
+// canonical norm, X = Xn / nrm, convergence test against x0.  One work-group per graph; every
+// later iteration streams S.  Writes X, iters_done[g] = 1 and stop[g] (1: converged).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mpm_first_iter_kernel(
+    const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
+    const int32_t *__restrict__ Rarr, int r_max, int ld, int64_t stride, float *__restrict__ X, int ldx,
+    int64_t strideX, float tol, int early_stop, int32_t *__restrict__ iters_done,
+    int32_t *__restrict__ stop) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float *red = lds_all;                                  // [16]
+  float &s_nrm = lds_all[16];
+  float *Xn = lds_all + kCtlFloats;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  constexpr int nt = 256;
+  const int R = Rarr[g];
+  if (R <= 0 || R > r_max) {       // nothing to iterate / reported by the queue's set-up kernel
+    if (tid == 0) {
+      iters_done[g] = 0;
+      stop[g] = 1;
+    }
+    return;
+  }
+  const int R2 = R * R;
+  float *pmax = Xn + ((R2 + 3) & ~3), *pmin = pmax + R;
+  const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
+  float *Xg = X + g * strideX;
+  const float x0 = (float)(1.0 / (double)R);
+  for (int a = tid; a < R; a += nt) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int b = 0; b < R; ++b) {
+      if (b == a) continue;
+      const float v = Pg[(int64_t)a * ld + b];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    pmax[a] = R > 1 ? mx : 0.0f;
+    pmin[a] = R > 1 ? mn : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < R2; e += nt) {
+    const int i = e / R, a = e - i * R;
+    const float *arow = Ag + (int64_t)i * ld;
+    const float pa = pmax[a], pn = pmin[a];
+    const float et = column_sum(
+        [&](int jj) {
+          if (jj == i) return 0.0f;
+          const float aij = arow[jj];
+          const float m = fmaxf(0.0f, aij >= 0.0f ? aij * pa : aij * pn);
+          return m * x0;
+        },
+        a, R);
+    Xn[e] = x0 * NSg[(int64_t)i * ld + a] + et;
+  }
+  __syncthreads();
+  const int n8 = R2 & ~7;
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8) acc = norm_chain(Xn, n8, tid, acc);
+    const float nrm = norm_finish(acc, Xn + n8, R2 - n8);
+    if (tid == 0) s_nrm = nrm;
+  }
+  __syncthreads();
+  const float nrm = s_nrm;
+  float dmax = 0.f;
+  bool isnan_any = false;
+  for (int e = tid; e < R2; e += nt) {
+    const float v = Xn[e] / nrm;
+    const int r = e / R, c = e - r * R;
+    const float d = fabsf(v - x0);
+    isnan_any |= (d != d);
+    dmax = fmaxf(dmax, d);
+    Xg[(int64_t)r * ldx + c] = v;
+  }
+  if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
+  for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = dmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    iters_done[g] = 1;
+    stop[g] = (early_stop && d < tol) ? 1 : 0;
+  }
+}
 
 // ---------------------------------------------------------------------------
 // Fused S-free MPM: one work-group per graph, Pt (P transposed, zero diagonal),
@@ -1236,14 +1335,17 @@ static inline int64_t mpm_queue_cap(int n_graphs, int r_max) {
 }
 
 int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
-  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (granules) | arrive
+  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (granules) | arrive | stop flags
   return pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 + pad256(8 * mpm_queue_cap(n_graphs, ldx)) +
-         pad256(4LL * n_graphs);
+         2 * pad256(4LL * n_graphs);
 }
 
-int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
-                    int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
-                    float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+// first_iter_done: the first iteration was computed by mpm_first_iter_kernel (iters_done and the
+// stop flags in the workspace are set); the launch streams iterations 2..iters
+static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                             int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                             float tol, int early_stop, int32_t *d_iters_done, void *d_ws,
+                             bool first_iter_done, void *stream) {
   GVAE_REQUIRE(d_S && d_S_off && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "mpm_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
@@ -1274,6 +1376,8 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   q.slots = (unsigned long long *)w;
   w += pad256(8 * mpm_queue_cap(n_graphs, ldx));
   q.arrive = (int32_t *)w;
+  w += pad256(4LL * n_graphs);
+  const int32_t *first_stop = first_iter_done ? (const int32_t *)w : nullptr;
   const int64_t n_items = mpm_queue_cap(n_graphs, r_max);
   q.cap = (unsigned)n_items;
   const int64_t strideXnew = (int64_t)ldx * ldx;
@@ -1317,7 +1421,7 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
 #endif
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
-                     s_layout, d_iters_done);
+                     s_layout, d_iters_done, first_stop, iters);
   {
     ProfileScope ps(F_MPM_ITER, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
@@ -1327,6 +1431,51 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
   hipLaunchKernelGGL(mpm_queue_check_kernel, dim3(ceil_div(n_graphs, 256)), dim3(256), 0, s, q,
                      n_graphs, d_iters_done);
   return check_launch("mpm_stream");
+}
+
+int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                    int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                    float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+  return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
+                           early_stop, d_iters_done, d_ws, false, stream);
+}
+
+int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                      float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_S && d_S_off && d_X && d_iters_done && d_ws, GVAE_EINVAL,
+               "match_stream: null pointer");
+  GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
+               "match_stream: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d iters=%d)", n_graphs, r_max,
+               ld, ldx, iters);
+  int rc = gvae_edge_sim(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, stream);
+  if (rc) return rc;
+  if (n_graphs == 0 || iters == 0)
+    return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters,
+                             tol, early_stop, d_iters_done, d_ws, false, stream);
+  GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "match_stream: more than 65535 graphs per call");
+  const size_t lds = sizeof(float) * (kCtlFloats + (((size_t)r_max * r_max + 3) & ~(size_t)3) +
+                                      2 * (size_t)r_max);
+  GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "match_stream: r_max=%d needs %zu bytes of LDS", r_max,
+               lds);
+  hipStream_t s = (hipStream_t)stream;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)mpm_first_iter_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "match_stream: cannot reserve %zu bytes of LDS: %s",
+                 lds, hipGetErrorString(e));
+  }
+  // the stop flags sit behind the arrival counters in the workspace (see mpm_stream_launch)
+  int32_t *stop = (int32_t *)((char *)d_ws + pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 +
+                              pad256(8 * mpm_queue_cap(n_graphs, ldx)) + pad256(4LL * n_graphs));
+  hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(256), lds, s, d_A, d_P, d_NS, d_R,
+                     r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, d_iters_done, stop);
+  rc = check_launch("match_stream");
+  if (rc) return rc;
+  if (iters == 1) return GVAE_OK;
+  return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
+                           early_stop, d_iters_done, d_ws, true, stream);
 }
 
 static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,

@@ -369,10 +369,9 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
       const int64_t NN = (int64_t)N * N;
       for (int c = 0; c < nc; ++c) {
         const int g0 = cb[c], nb = cb[c + 1] - cb[c];
-        TRY(gvae_edge_sim(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN, r_max,
-                          GVAE_S_PADDED, d_S, d_S_off + g0, s));
-        TRY(gvae_mpm_stream(d_S, d_S_off + g0, GVAE_S_PADDED, d_R + g0, nb, r_max, w.X + g0 * NN, N,
-                            NN, mpm_iters, tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
+        TRY(gvae_match_stream(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
+                              r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
+                              tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
       }
     } else if (do_assign) {
       // S-free MPM with the assignment as its epilogue

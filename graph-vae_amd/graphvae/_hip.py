@@ -51,6 +51,9 @@ def lib() -> ctypes.CDLL:
         L.gvae_mpm_stream.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
                                       c_void_p]
+        L.gvae_match_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                        c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]
         L.gvae_mpm_fused.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                      c_int, c_void_p, c_int, c_int64, c_int, c_float, c_int,
                                      c_void_p, c_void_p]
@@ -174,6 +177,25 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
                                  X.data_ptr(), N, N * N, iters, tol, int(early_stop),
                                  done.data_ptr(), ws.data_ptr(), _stream()))
     return done
+
+
+def match_stream(A, P, NS, R, R_host, X, iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
+                 layout: int = S_PADDED):
+    """Similarity tensor + streamed MPM from the uniform start in one library call
+    (gvae_match_stream): returns (S, S_off, iterations); X (G, N, N) is output only."""
+    _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
+    _dev(X, torch.float32)
+    G, N, _ = A.shape
+    offs, total = s_offsets(R_host, layout)
+    S = torch.empty(max(total, 4), dtype=torch.float32, device=A.device)
+    S_off = torch.tensor(offs, dtype=torch.int64, device=A.device)
+    done = torch.empty(G, dtype=torch.int32, device=A.device)
+    ws = torch.empty(lib().gvae_mpm_stream_ws_bytes(G, X.shape[1]), dtype=torch.uint8, device=A.device)
+    _check(lib().gvae_match_stream(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N, N * N,
+                                   max(R_host), layout, S.data_ptr(), S_off.data_ptr(), X.data_ptr(),
+                                   X.shape[1], X.shape[1] * X.shape[2], iters, tol, int(early_stop),
+                                   done.data_ptr(), ws.data_ptr(), _stream()))
+    return S, S_off, done
 
 
 def mpm_fused_supported(r_max: int) -> bool:

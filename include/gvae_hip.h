@@ -91,6 +91,19 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                     int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
 
+/* gvae_edge_sim followed by gvae_mpm_stream from the uniform start X0 = 1/R of
+ * graphvae/models/model.py:317, in one call (what the step's streamed matching uses).  The
+ * tensor is written as by gvae_edge_sim; the FIRST iteration is computed without reading it
+ * back: with a uniform X0, max_b S[i,j,a,b]*x0 = (max_b S[i,j,a,b])*x0 exactly (rounding is
+ * monotone), and the row maximum of S is max(0, A[i,j]*max_{b!=a} P[a,b]) (the minimum over b
+ * when A[i,j] < 0), so that iteration costs O(R^3) per graph instead of one pass over S; every
+ * later iteration streams S.  d_X is output only.  Same X, same iteration counts as the two
+ * calls, bit for bit.  d_ws: gvae_mpm_stream_ws_bytes. */
+int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                      float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Max-pool matching without S: same recurrence and same bits as
  * gvae_edge_sim + gvae_mpm_stream when A is 0/1 with unit diagonal and P >= 0,

@@ -59,6 +59,14 @@ def _run_all(hip, As, Ps, cfg, N=None, check_stream=True):
         done_s = hip.mpm_stream(S, S_off, R, max(Rh), Xs, iters, tol, es)
         out["S"], out["S_off"] = S.cpu().numpy(), S_off.cpu().numpy()
         out["X_stream"], out["done_stream"] = Xs.cpu().numpy(), done_s.cpu().numpy()
+        # tensor + MPM in one call (first iteration without reading S back): same bits
+        Xm = torch.full_like(Xs, float("nan"))
+        S2, _off2, done_m = hip.match_stream(A, P, NS, R, Rh, Xm, iters, tol, es, layout=hip.S_DENSE)
+        assert torch.equal(done_m, done_s)
+        for g, r in enumerate(Rh):
+            o = int(S_off[g])
+            assert torch.equal(S2[o:o + r ** 4], S[o:o + r ** 4]), (g, r)
+            assert torch.equal(Xm[g, :r, :r], Xs[g, :r, :r]), (g, r)
         if not fused_ok:
             Xf, out["X_fused"], out["done_fused"] = Xs, out["X_stream"], out["done_stream"]
     perm, status = hip.lsap(Xf, R, max(Rh))
@@ -193,6 +201,46 @@ def test_fused_assign_beyond_resident_capacity(hip):
         X, done = ora.mpm_sfree(As[k], Ps[k])
         assert o["done_fused"][k] == done and np.array_equal(o["X_fused"][k, :R, :R], X)
         assert np.array_equal(o["perm"][k, :R], ora.assign_perm(X))
+
+
+@pytest.mark.parametrize("iters,es", [(0, True), (1, True), (1, False), (2, True), (7, False), (50, True)])
+def test_match_stream_first_iteration_shortcut(hip, iters, es):
+    """gvae_match_stream computes the first iteration from row maxima of S instead of
+    streaming S: against edge_sim + mpm_stream on weighted adjacencies (zero, positive and
+    negative entries, where the row maximum comes from the smallest probability), one-node
+    graphs, odd sizes and graphs that converge in the first iteration."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    sizes = (1, 2, 3, 5, 9, 16, 21, 32, 33, 47, 50, 64, 1, 70)
+    As, Ps = [], []
+    for k, R in enumerate(sizes):
+        w = rng.normal(0.5, 1.0, (R, R)).astype(np.float32) * (rng.random((R, R)) < 0.5)
+        if k % 3 == 0:
+            w = (w != 0).astype(np.float32)                      # plain 0/1 adjacency
+        up = np.triu(w, 1)
+        As.append((up + up.T + np.eye(R, dtype=np.float32)).astype(np.float32))
+        spread = 0.0 if k == 5 else 1.5                           # k == 5: constant P, converges at once
+        lg = np.triu(rng.normal(0, spread, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    N = max(sizes)
+    A = torch.from_numpy(_pack(As, N)).to(dev)
+    P = torch.from_numpy(_pack(Ps, N)).to(dev)
+    Rh = list(sizes)
+    R = torch.tensor(Rh, dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    for layout in (hip.S_DENSE, hip.S_PADDED):
+        S, S_off = hip.edge_sim(A, P, NS, R, Rh, layout)
+        Xs = hip.x0_uniform(Rh, N, dev)
+        done_s = hip.mpm_stream(S, S_off, R, N, Xs, iters, 1e-4, es, layout=layout)
+        Xm = hip.x0_uniform(Rh, N, dev)
+        S2, _o, done_m = hip.match_stream(A, P, NS, R, Rh, Xm, iters, 1e-4, es, layout=layout)
+        assert done_m.cpu().tolist() == done_s.cpu().tolist()
+        for g, r in enumerate(Rh):
+            o, n = int(S_off[g]), r ** 3 * (r if layout == hip.S_DENSE else (r + 3) // 4 * 4)
+            assert torch.equal(S2[o:o + n], S[o:o + n]), (layout, g, r)
+            assert torch.equal(Xm[g, :r, :r], Xs[g, :r, :r]), (layout, g, r)
+    if iters >= 2 and es:
+        assert min(done_s.cpu().tolist()) == 1       # some graph did stop after the first iteration
 
 
 def test_random_ragged_batch_vs_oracle(hip):
