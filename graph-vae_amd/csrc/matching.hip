@@ -859,17 +859,16 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
 // canonical norm, X = Xn / nrm, convergence test against x0.  One work-group per graph; every
 // later iteration streams S.  Writes X, iters_done[g] = 1 and stop[g] (1: converged).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mpm_first_iter_kernel(
+__global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int r_max, int ld, int64_t stride, float *__restrict__ X, int ldx,
-    int64_t strideX, float tol, int early_stop, int32_t *__restrict__ iters_done,
+    int64_t strideX, float tol, int early_stop, int a_in_lds, int32_t *__restrict__ iters_done,
     int32_t *__restrict__ stop) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   float *red = lds_all;                                  // [16]
   float &s_nrm = lds_all[16];
   float *Xn = lds_all + kCtlFloats;
-  const int g = blockIdx.x, tid = threadIdx.x;
-  constexpr int nt = 256;
+  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int R = Rarr[g];
   if (R <= 0 || R > r_max) {       // nothing to iterate / reported by the queue's set-up kernel
     if (tid == 0) {
@@ -878,26 +877,40 @@ __global__ __launch_bounds__(256) void mpm_first_iter_kernel(
     }
     return;
   }
-  const int R2 = R * R;
-  float *pmax = Xn + ((R2 + 3) & ~3), *pmin = pmax + R;
+  const int R2 = R * R, R2p = (R2 + 3) & ~3;
+  float *pmax = Xn + R2p, *pmin = pmax + R;
+  float *As = pmin + R;            // R*R copy of A when it fits (a_in_lds), else A is read in place
   const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
   float *Xg = X + g * strideX;
   const float x0 = (float)(1.0 / (double)R);
-  for (int a = tid; a < R; a += nt) {
+  // row extrema of P without its diagonal: 8 lanes per row, folded with three shuffles
+  for (int a0 = 0; a0 < R; a0 += nt >> 3) {
+    const int a = a0 + (tid >> 3), l = tid & 7;
     float mx = -INFINITY, mn = INFINITY;
-    for (int b = 0; b < R; ++b) {
-      if (b == a) continue;
-      const float v = Pg[(int64_t)a * ld + b];
-      mx = fmaxf(mx, v);
-      mn = fminf(mn, v);
+    if (a < R)
+      for (int b = l; b < R; b += 8) {
+        const float v = Pg[(int64_t)a * ld + b];
+        mx = b == a ? mx : fmaxf(mx, v);
+        mn = b == a ? mn : fminf(mn, v);
+      }
+    for (int off = 4; off > 0; off >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      mn = fminf(mn, __shfl_xor(mn, off, 64));
     }
-    pmax[a] = R > 1 ? mx : 0.0f;
-    pmin[a] = R > 1 ? mn : 0.0f;
+    if (a < R && l == 0) {
+      pmax[a] = R > 1 ? mx : 0.0f;
+      pmin[a] = R > 1 ? mn : 0.0f;
+    }
   }
+  if (a_in_lds)
+    for (int e = tid; e < R2; e += nt) {
+      const int i = e / R, j = e - i * R;
+      As[e] = Ag[(int64_t)i * ld + j];
+    }
   __syncthreads();
   for (int e = tid; e < R2; e += nt) {
     const int i = e / R, a = e - i * R;
-    const float *arow = Ag + (int64_t)i * ld;
+    const float *arow = a_in_lds ? As + i * R : Ag + (int64_t)i * ld;
     const float pa = pmax[a], pn = pmin[a];
     const float et = column_sum(
         [&](int jj) {
@@ -934,7 +947,8 @@ __global__ __launch_bounds__(256) void mpm_first_iter_kernel(
   if ((tid & 63) == 0) red[tid >> 6] = dmax;
   __syncthreads();
   if (tid == 0) {
-    const float d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float d = red[0];
+    for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
     iters_done[g] = 1;
     stop[g] = (early_stop && d < tol) ? 1 : 0;
   }
@@ -1455,10 +1469,12 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
     return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters,
                              tol, early_stop, d_iters_done, d_ws, false, stream);
   GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "match_stream: more than 65535 graphs per call");
-  const size_t lds = sizeof(float) * (kCtlFloats + (((size_t)r_max * r_max + 3) & ~(size_t)3) +
-                                      2 * (size_t)r_max);
+  const size_t r2 = (size_t)r_max * r_max;
+  size_t lds = sizeof(float) * (kCtlFloats + ((r2 + 3) & ~(size_t)3) + 2 * (size_t)r_max);
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "match_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
+  const int a_in_lds = lds + sizeof(float) * r2 <= kMaxDynLds;    // else A is read in place (L2)
+  if (a_in_lds) lds += sizeof(float) * r2;
   hipStream_t s = (hipStream_t)stream;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_first_iter_kernel,
@@ -1469,8 +1485,9 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
   // the stop flags sit behind the arrival counters in the workspace (see mpm_stream_launch)
   int32_t *stop = (int32_t *)((char *)d_ws + pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 +
                               pad256(8 * mpm_queue_cap(n_graphs, ldx)) + pad256(4LL * n_graphs));
-  hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(256), lds, s, d_A, d_P, d_NS, d_R,
-                     r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, d_iters_done, stop);
+  hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(r_max >= 48 ? 1024 : 256), lds, s, d_A,
+                     d_P, d_NS, d_R, r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, a_in_lds,
+                     d_iters_done, stop);
   rc = check_launch("match_stream");
   if (rc) return rc;
   if (iters == 1) return GVAE_OK;
