@@ -98,7 +98,8 @@ def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        on = device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -171,6 +172,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from graphvae.train.train_ddp import require_one_gpu_per_rank
+        try:
+            require_one_gpu_per_rank(world, backend)       # RCCL: two ranks on one device stall
+        except RuntimeError as e:
+            raise SystemExit(f"bench.py: {e}")
         if backend == "nccl":                              # "nccl" is RCCL on ROCm
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -192,7 +198,8 @@ def main():
         host_batches = host_batches or host
         note(f"{leg}: model and batches ready")
         if dist.is_initialized():
-            dist.broadcast(model.flat_parameters(), src=0)
+            from graphvae.train.train_ddp import HostStagedCollectives
+            HostStagedCollectives().broadcast(model.flat_parameters(), src=0)
             note("parameters broadcast")
         # as the trainer runs it: matching half on a second stream, steps pipelined
         step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world, force_collectives=force_dist,

@@ -293,12 +293,14 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
     const float *__restrict__ beta, const float *__restrict__ run_mean,
     const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
     float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
-    float *__restrict__ var_unb_o) {
+    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o) {
   __shared__ double sh[4][64];
   const int g = blockIdx.y, tid = threadIdx.x;
   const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
   const bool cv = c < H;
   const int nx = n_x[g];
+  // which statistics this forward normalised with: the backward of the batch reads it
+  if (mode_o && g == 0 && blockIdx.x == 0 && tid == 0) mode_o[0] = train;
   const float *Yg = Y + (int64_t)g * N * H;
   float *Og = out + (int64_t)g * N * H;
   const float b = cv ? bias[c] : 0.0f;
@@ -344,9 +346,9 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
 int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
                        const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
                        int H, int train, float *out, float *mean, float *invstd, float *var_unb,
-                       hipStream_t s) {
+                       int32_t *mode_out, hipStream_t s) {
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, Y, bias, gamma,
-                     beta, run_mean, run_var, n_x, N, H, train, out, mean, invstd, var_unb);
+                     beta, run_mean, run_var, n_x, N, H, train, out, mean, invstd, var_unb, mode_out);
   return check_launch("bn_relu_fwd");
 }
 
@@ -388,16 +390,19 @@ int launch_bn_running_update(const float *mean, const float *var_unb, int B, int
   return check_launch("bn_running_update");
 }
 
-// backward of relu(BN(Y + bias)) in training mode (sums in double):
-//   dpre = dOut * (out > 0);  dbeta = sum dpre;  dot = sum dpre * (y - mean)
-//   dgamma = dot * invstd;   dY = (dpre - dbeta/n - (y - mean) * dot * invstd^2 / n) * invstd * gamma
-//   rows >= n_x: 0
+// backward of relu(BN(Y + bias)) (sums in double):
+//   dpre = dOut * (out > 0);  dbeta = sum dpre;  dot = sum dpre * (y - mean);  dgamma = dot * invstd
+//   batch statistics (training forward):
+//     dY = (dpre - dbeta/n - (y - mean) * dot * invstd^2 / n) * invstd * gamma
+//   running statistics (eval forward; mean / invstd are constants of the input):
+//     dY = dpre * invstd * gamma
+//   rows >= n_x: 0.  mode[0] != 0: the forward of this batch used batch statistics.
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     const float *__restrict__ dOut, const float *__restrict__ Y, const float *__restrict__ bias,
     const float *__restrict__ out, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ invstd, const int32_t *__restrict__ n_x, int N, int H,
-    float *__restrict__ dY, float *__restrict__ dgamma_p, float *__restrict__ dbeta_p,
-    float *__restrict__ dbias_p) {
+    const int32_t *__restrict__ mode, float *__restrict__ dY, float *__restrict__ dgamma_p,
+    float *__restrict__ dbeta_p, float *__restrict__ dbias_p) {
   __shared__ double sh[4][64];
   const int g = blockIdx.y, tid = threadIdx.x;
   const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
@@ -417,8 +422,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   sb = quad_rows_sum(sb, sh, rl, cl);
   dot = quad_rows_sum(dot, sh, rl, cl);
   const float ga = cv ? gamma[c] : 0.0f;
-  const float dmean = (float)(sb / (double)nx);
-  const float k = (float)(dot * (double)is * (double)is / (double)nx);
+  const bool batch_stats = mode[0] != 0;
+  const float dmean = batch_stats ? (float)(sb / (double)nx) : 0.0f;
+  const float k = batch_stats ? (float)(dot * (double)is * (double)is / (double)nx) : 0.0f;
   double sdy = 0.0;
   if (cv) for (int i = rl; i < N; i += 4) {
     const int64_t e = base + (int64_t)i * H + c;
@@ -441,10 +447,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 
 int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
                        const float *gamma, const float *mean, const float *invstd,
-                       const int32_t *n_x, int B, int N, int H, float *dY, float *dgamma_p,
-                       float *dbeta_p, float *dbias_p, hipStream_t s) {
+                       const int32_t *n_x, int B, int N, int H, const int32_t *mode, float *dY,
+                       float *dgamma_p, float *dbeta_p, float *dbias_p, hipStream_t s) {
   hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, dOut, Y, bias,
-                     out, gamma, mean, invstd, n_x, N, H, dY, dgamma_p, dbeta_p, dbias_p);
+                     out, gamma, mean, invstd, n_x, N, H, mode, dY, dgamma_p, dbeta_p, dbias_p);
   return check_launch("bn_relu_bwd");
 }
 

@@ -45,17 +45,19 @@ int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, 
                         float *Ahat, hipStream_t s);
 // BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics
 // (written to mean / invstd / var_unbiased, each (B,H)); else running statistics.
+// mode_out (device, nullable) receives `train`: launch_bn_relu_bwd of the same batch reads it.
 int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
                        const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
                        int H, int train, float *out, float *mean, float *invstd, float *var_unb,
-                       hipStream_t s);
+                       int32_t *mode_out, hipStream_t s);
 int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
                              float *run_mean, float *run_var, hipStream_t s);
-// dY (B,N,H) from dOut; per-graph partial sums dgamma_p, dbeta_p, dbias_p (B,H)
+// dY (B,N,H) from dOut; per-graph partial sums dgamma_p, dbeta_p, dbias_p (B,H).  mode (device):
+// non-zero if the forward used batch statistics, zero if it used the running ones.
 int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
                        const float *gamma, const float *mean, const float *invstd,
-                       const int32_t *n_x, int B, int N, int H, float *dY, float *dgamma_p,
-                       float *dbeta_p, float *dbias_p, hipStream_t s);
+                       const int32_t *n_x, int B, int N, int H, const int32_t *mode, float *dY,
+                       float *dgamma_p, float *dbeta_p, float *dbias_p, hipStream_t s);
 // out[c] (+)= sum_r M[r*ld + c]   (rows summed in index order)
 int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
                   hipStream_t s);

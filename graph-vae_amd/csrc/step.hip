@@ -40,6 +40,7 @@ struct Workspace {
   float *splitk;
   int64_t splitk_floats;
   int32_t *status;
+  int32_t *bn_mode;   // [0]: the forward of this batch normalised with batch statistics
   char *mpm_ws;
   int64_t bytes;
 };
@@ -79,6 +80,7 @@ static Workspace carve(const gvae_dims *d, int B, char *base) {
   w.splitk_floats = GEMM_GROUP_MAX * (512 * 4096 + mn);   // room for a whole group of split GEMMs
   w.splitk = take(w.splitk_floats);
   w.status = reinterpret_cast<int32_t *>(take(B));
+  w.bn_mode = reinterpret_cast<int32_t *>(take(4));
   w.mpm_ws = reinterpret_cast<char *>(take((gvae_mpm_stream_ws_bytes(B, (int)N) + 3) / 4));
   w.bytes = off;
   return w;
@@ -304,11 +306,11 @@ static int forward_model(const gvae_dims *d, const float *d_params, float *d_bn_
   TRY(linear_fwd(d_x, F, P.p[GVAE_P_CONV1_W], nullptr, w.H0a, B * N, H, F, 0, s));
   TRY(aggregate(w.Ahat, w.H0a, w.Y1, B, N, H, s));
   TRY(launch_bn_relu_fwd(w.Y1, P.p[GVAE_P_CONV1_B], P.p[GVAE_P_BN1_W], P.p[GVAE_P_BN1_B], rm1, rv1,
-                         d_n_x, B, N, H, train, w.H1, w.mean1, w.invstd1, w.varu1, s));
+                         d_n_x, B, N, H, train, w.H1, w.mean1, w.invstd1, w.varu1, w.bn_mode, s));
   TRY(linear_fwd(w.H1, H, P.p[GVAE_P_CONV2_W], nullptr, w.H0b, B * N, H, H, 0, s));
   TRY(aggregate(w.Ahat, w.H0b, w.Y2, B, N, H, s));
   TRY(launch_bn_relu_fwd(w.Y2, P.p[GVAE_P_CONV2_B], P.p[GVAE_P_BN2_W], P.p[GVAE_P_BN2_B], rm2, rv2,
-                         d_n_x, B, N, H, train, w.H2, w.mean2, w.invstd2, w.varu2, s));
+                         d_n_x, B, N, H, train, w.H2, w.mean2, w.invstd2, w.varu2, nullptr, s));
   if (train) {
     TRY(launch_bn_running_update(w.mean1, w.varu1, B, H, 0.1f, rm1, rv1, s));
     TRY(launch_bn_running_update(w.mean2, w.varu2, B, H, 0.1f, rm2, rv2, s));
@@ -536,7 +538,7 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   // encoder layer 2
   TRY(launch_pool_bwd(w.dgvec, d_n_x, d_R, B, N, H, w.dAct, s));
   TRY(launch_bn_relu_bwd(w.dAct, w.Y2, P.p[GVAE_P_CONV2_B], w.H2, P.p[GVAE_P_BN2_W], w.mean2,
-                         w.invstd2, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
+                         w.invstd2, d_n_x, B, N, H, w.bn_mode, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
   {
     ColsumGroup cs;
     cs.add(w.dgam_p, B, H, H, G(GVAE_P_BN2_W));
@@ -553,7 +555,7 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   }
   // encoder layer 1
   TRY(launch_bn_relu_bwd(w.dAct, w.Y1, P.p[GVAE_P_CONV1_B], w.H1, P.p[GVAE_P_BN1_W], w.mean1,
-                         w.invstd1, d_n_x, B, N, H, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
+                         w.invstd1, d_n_x, B, N, H, w.bn_mode, w.dY, w.dgam_p, w.dbet_p, w.dbias_p, s));
   {
     ColsumGroup cs;
     cs.add(w.dgam_p, B, H, H, G(GVAE_P_BN1_W));

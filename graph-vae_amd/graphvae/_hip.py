@@ -72,12 +72,17 @@ def _check(rc: int) -> None:
 
 
 def _stream() -> int:
+    """The current stream of the CURRENT device: kernel launches go to the current device, so
+    every tensor handed to the library must live there (`_dev` checks it)."""
     return torch.cuda.current_stream().cuda_stream
 
 
 def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
     if not t.is_cuda:
         raise GvaeHipError("expected a device tensor (the HIP path has no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise GvaeHipError(f"tensor on {t.device} but the current device is cuda:"
+                           f"{torch.cuda.current_device()}: wrap the call in torch.cuda.device(...)")
     if t.dtype != dtype or not t.is_contiguous():
         raise GvaeHipError(f"expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
     return t

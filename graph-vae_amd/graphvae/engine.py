@@ -239,6 +239,11 @@ class StepEngine:
         if mode != MATCH_STREAM:
             return None, None, None, 0
         self._ensure_S(batch.r_host)
+        # the shared buffers are used on whichever stream runs the matching: the allocator must
+        # not hand their memory out again while that stream still reads it
+        cur = torch.cuda.current_stream(self.device)
+        self._S.record_stream(cur)
+        self._S_off.record_stream(cur)
         return (self._S.data_ptr(), self._S_off.data_ptr(), self._S_chunks, len(self._S_chunks) - 1)
 
     def forward(self, params: torch.Tensor, bn_state: torch.Tensor, batch: DenseGraphBatch,

@@ -99,7 +99,10 @@ class _StepFunction(torch.autograd.Function):
                                "activations of the most recent forward only")
         up = torch.stack([d_rec if d_rec is not None else torch.zeros_like(eng.out4[0]),
                           d_kl if d_kl is not None else torch.zeros_like(eng.out4[0])]).contiguous()
-        grads = model._grad_flat_buffer()
+        # a fresh buffer per call: autograd keeps the returned tensors as .grad without copying,
+        # so views of a persistent buffer would alias the next backward's output (and
+        # accumulation over micro-batches would add a gradient onto itself)
+        grads = torch.zeros_like(model._flat)
         eng.backward(model._flat, model._pos_weight_dev(), grads, 1.0, 1.0, up)
         views = model._views_of(grads)
         return (None, None, None, None) + tuple(views)
@@ -135,7 +138,6 @@ class GraphVAE(nn.Module):
         self._offsets, self._sizes, self._flat_len = None, None, None
         self._flat = None
         self._bn_state = None
-        self._grad_flat = None
         self._engine = None
         self._flatten()
 
@@ -192,7 +194,6 @@ class GraphVAE(nn.Module):
             view.copy_(mod._buffers[key])
             mod._buffers[key] = view
         self._flat, self._bn_state = flat, bn
-        self._grad_flat = None
         self._engine = None
 
     def _apply(self, fn, *a, **k):
@@ -207,11 +208,6 @@ class GraphVAE(nn.Module):
     def bn_state(self) -> torch.Tensor:
         """[bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var] flat."""
         return self._bn_state
-
-    def _grad_flat_buffer(self) -> torch.Tensor:
-        if self._grad_flat is None or self._grad_flat.device != self._flat.device:
-            self._grad_flat = torch.zeros_like(self._flat)
-        return self._grad_flat
 
     def _pos_weight_dev(self) -> torch.Tensor:
         return self.pos_weight_global.reshape(1)

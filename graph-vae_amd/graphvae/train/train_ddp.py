@@ -133,6 +133,61 @@ def shard_indices(n: int, world: int, rank: int, shuffle: bool, epoch: int, seed
     return idx[rank:total:world]
 
 
+# --------------------------------------------------------------------------- collectives
+class HostStagedCollectives:
+    """The step's collectives on flat device tensors, for any torch.distributed backend.
+
+    RCCL ("nccl") collectives are stream-ordered device operations and take the tensor as it is.
+    Every other backend (gloo) reduces on the host.  c10d's own handling of a device tensor there
+    (a high-priority pool stream, pinned temporaries and event waits inside a worker thread)
+    stalled within a few steps on MI355X whenever kernels of the step were still in flight when
+    the collective was issued: the device work queued ahead of the collective never completed on
+    one rank (benchmarks/rehearse_dist.py shows it).  So the ordering is made explicit here
+    instead: copy to a pinned buffer on the current stream, synchronise THAT stream, run the
+    collective on the host copy, copy back on the same stream."""
+
+    def __init__(self, group=None) -> None:
+        self.group = group
+        self._pinned = {}
+
+    def _direct(self, t: torch.Tensor) -> bool:
+        return not t.is_cuda or dist.get_backend(self.group) == "nccl"
+
+    def _staged(self, t: torch.Tensor, fn) -> None:
+        key = (t.numel(), t.dtype)
+        h = self._pinned.get(key)
+        if h is None:
+            h = self._pinned[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+        h.copy_(t.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        fn(h)
+        t.reshape(-1).copy_(h, non_blocking=True)
+
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
+        if self._direct(t):
+            dist.all_reduce(t, op=op, group=self.group)
+        else:
+            self._staged(t, lambda h: dist.all_reduce(h, op=op, group=self.group))
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> None:
+        if self._direct(t):
+            dist.broadcast(t, src=src, group=self.group)
+        else:
+            self._staged(t, lambda h: dist.broadcast(h, src=src, group=self.group))
+
+
+def require_one_gpu_per_rank(world: int, backend: str = "nccl") -> None:
+    """RCCL needs a device of its own for every rank of a node: two ranks on one device do not
+    fail, they stall inside the first collective.  Raised before any collective is issued."""
+    n_dev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if backend == "nccl" and local_world > n_dev:
+        raise RuntimeError(
+            f"{local_world} ranks on this node but only {n_dev} visible GPU(s): RCCL needs one GPU "
+            "per rank (launch with --nproc-per-node <= GPUs; to rehearse more ranks than GPUs use "
+            "the gloo backend)")
+
+
 # --------------------------------------------------------------------------- the step
 def concurrent_stream(device, others=(), tries: int = 4) -> "torch.cuda.Stream":
     """A stream whose kernels run beside the current stream's (and beside those of `others`).
@@ -142,9 +197,12 @@ def concurrent_stream(device, others=(), tries: int = 4) -> "torch.cuda.Stream":
     depends on how many streams other libraries (RCCL, c10d) took before.  Up to `tries`
     consecutive pool streams are probed: about 2 ms of memory-bound kernels go to a reference
     stream, a one-element kernel to the candidate; the candidate passes if its kernel ends
-    while the others still run.  (A high-priority stream also gets a queue of its own, but
-    cross-waits between priority classes deadlocked intermittently under per-step host
-    synchronisation: not used.)"""
+    while the others still run.  When no candidate passes (or tries == 0) the last pool stream
+    is returned all the same: the step is then correct but its halves run one after the other.
+    Only default-priority streams are handed out.  (A high-priority stream also gets a queue of
+    its own, but with this step's kernels in flight, event waits between a high-priority and a
+    default-priority stream stalled the device within a few steps, although the event graph
+    has no cycle; TrainStep asserts the priority of the streams it is given.)"""
     refs = [torch.cuda.current_stream(device)] + list(others)
     ballast = torch.empty(64 << 20, dtype=torch.float32, device=device)    # 256 MiB
     flag = torch.zeros(1, device=device)
@@ -173,7 +231,9 @@ def concurrent_stream(device, others=(), tries: int = 4) -> "torch.cuda.Stream":
             break
     torch.cuda.synchronize(device)
     concurrent_stream.last_probe = (len(held), chosen is not None)     # for logs
-    return chosen if chosen is not None else held[-1]
+    if chosen is None:
+        chosen = held[-1] if held else torch.cuda.Stream(device=device)
+    return chosen
 
 
 class TrainStep:
@@ -183,7 +243,7 @@ class TrainStep:
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
                  world: int = 1, group=None, sync_bn_buffers: bool = False, engine=None,
                  force_collectives: bool = False, overlap_matching: bool = True,
-                 pipeline: bool = False) -> None:
+                 pipeline: bool = False, probe_tries: int = 4) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
         model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
         `sync_bn_buffers`: broadcast rank 0's BatchNorm running statistics before every forward,
@@ -204,13 +264,16 @@ class TrainStep:
         workspaces alternate; a workspace is reused only after its matching has finished).
         The returned loss tensor, `model.last_permutations()` and `loss_sum` are then valid on
         the current stream only after `wait()`; parameters, gradients and optimiser state never
-        depend on the matching and are always in stream order."""
+        depend on the matching and are always in stream order.
+        `probe_tries`: pool streams `concurrent_stream` may probe for the side streams."""
         self.model = model
+        self.probe_tries = int(probe_tries)
         self._engine = engine
         self.lr, self.weight_decay, self.clip_max = lr, weight_decay, clip_max
         self.world, self.group = world, group
         self.sync_bn_buffers = sync_bn_buffers
         self.collectives = world > 1 or force_collectives
+        self.comm = HostStagedCollectives(group)
         flat = model.flat_parameters()
         self.overlap_matching = bool(overlap_matching) and flat.is_cuda
         self.pipeline = bool(pipeline) and self.overlap_matching
@@ -254,7 +317,7 @@ class TrainStep:
     def sync_buffers(self) -> None:
         """Every rank takes rank 0's BatchNorm running statistics."""
         if self.collectives:
-            dist.broadcast(self.model.bn_state(), src=0, group=self.group)
+            self.comm.broadcast(self.model.bn_state(), src=0)
 
     def __call__(self, batch: DenseGraphBatch, beta: float, lr_scale: float,
                  eps: torch.Tensor | None = None) -> torch.Tensor:
@@ -263,21 +326,25 @@ class TrainStep:
         model = self.model
         if self.collectives and self.sync_bn_buffers:
             # DDP's broadcast_buffers: every forward starts from rank 0's running statistics
-            dist.broadcast(model.bn_state(), src=0, group=self.group)
+            self.comm.broadcast(model.bn_state(), src=0)
         eng = self._engine if self._engine is not None else model._engine_for(batch)
         if eps is None:
             eps = torch.randn(batch.num_graphs, model.z_dim, dtype=torch.float32, device=batch.device)
         overlap = self.overlap_matching and hasattr(eng, "forward_match_loss")
         if overlap:
             if self._side is None:
-                self._side = concurrent_stream(self.grads.device)
+                self._side = concurrent_stream(self.grads.device, tries=self.probe_tries)
                 self._ev_model = [torch.cuda.Event(), torch.cuda.Event()]
                 self._ev_mpm = [torch.cuda.Event(), torch.cuda.Event()]
                 self._ev_match = [None, None]
                 if self.pipeline:
                     # assignment + losses of step N (one wavefront per graph, latency-bound) run
                     # beside the similarity tensor and the MPM of step N+1
-                    self._tail = concurrent_stream(self.grads.device, others=[self._side])
+                    self._tail = concurrent_stream(self.grads.device, others=[self._side],
+                                                   tries=self.probe_tries)
+                for st in (self._side, self._tail):
+                    # event waits between priority classes stalled the device (see concurrent_stream)
+                    assert st is None or st.priority == 0, "side streams must have default priority"
             main = torch.cuda.current_stream(self.grads.device)
             k = self._slot
             if self.pipeline:
@@ -323,7 +390,7 @@ class TrainStep:
             self.loss_sum += (out4[0] + beta * out4[1]).double()
         eng.backward(model.flat_parameters(), model._pos_weight_dev(), self.grads, 1.0, beta)
         if self.collectives:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.all_reduce(self.grads)
         self.t += 1
         eng.adam_step(model.flat_parameters(), self.grads, self.m, self.v, self.t,
                       self.lr * lr_scale, weight_decay=self.weight_decay, clip_max=self.clip_max,
@@ -363,11 +430,6 @@ class DebugState(_NoDbg):
             self.wb.log({tag: value, "step": self.step})
 
 
-def finite_or_raise(t, name):
-    if not torch.isfinite(t).all():
-        raise FloatingPointError(f"{name} contains inf / nan")
-
-
 def _optional_loggers(args, rank: int):
     tb = wb = None
     if rank != 0:
@@ -394,14 +456,18 @@ def _ddp_worker(rank: int, world: int, args) -> None:
     use_gpu = torch.cuda.is_available()
     if not use_gpu:
         raise RuntimeError("graphvae.train.train_ddp needs a GPU (the HIP step has no CPU fallback)")
+    if dist.is_initialized() and dist.get_backend() != "nccl":
+        local_rank %= torch.cuda.device_count()      # gloo rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     spawned = False
     if world > 1 and not dist.is_initialized():
+        require_one_gpu_per_rank(world)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
         spawned = True
+    comm = HostStagedCollectives()
 
     # graphs: every rank builds the same list; rank 0's shuffle order is broadcast
     graphs, max_nodes = build_graph_list(args.dataset, args.max_nodes)
@@ -430,8 +496,8 @@ def _ddp_worker(rank: int, world: int, args) -> None:
     # rho over the full training set, identical on every rank (same data, same arithmetic)
     model.precompute_dataset_rho([dense_tr])
     if world > 1:
-        dist.broadcast(model.flat_parameters(), src=0)
-        dist.broadcast(model.bn_state(), src=0)
+        comm.broadcast(model.flat_parameters(), src=0)
+        comm.broadcast(model.bn_state(), src=0)
         dist.barrier()
 
     step_fn = TrainStep(model, args.lr, args.weight_decay, args.clip_max, world,
@@ -468,7 +534,7 @@ def _ddp_worker(rank: int, world: int, args) -> None:
         if getattr(model, "_engine", None) is not None:
             model._engine.check_matching()                  # once per epoch: faults of the matching kernels
         if world > 1:
-            dist.all_reduce(tot_tr, op=dist.ReduceOp.SUM)
+            comm.all_reduce(tot_tr)
         mean_tr = tot_tr.item() / max(1, len(dl_tr)) / world
 
         step_fn.sync_buffers()          # validation reads the running statistics: rank 0's, everywhere
@@ -480,7 +546,7 @@ def _ddp_worker(rank: int, world: int, args) -> None:
                 acc += (logs["rec"] + args.beta_final * logs["kl"]).double()
         tot_va = acc.clone()
         if world > 1:
-            dist.all_reduce(tot_va, op=dist.ReduceOp.SUM)
+            comm.all_reduce(tot_va)
         mean_va = tot_va.item() / max(1, len(dl_va)) / world
 
         if rank == 0:
@@ -543,8 +609,11 @@ def train(cfg) -> None:
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         world = int(os.environ["WORLD_SIZE"])
         if world > 1 and not dist.is_initialized():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
-            dist.init_process_group("nccl")
+            backend = os.environ.get("GVAE_DIST_BACKEND", "nccl")    # gloo: rehearsal on fewer GPUs
+            require_one_gpu_per_rank(world, backend)
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+                                  % torch.cuda.device_count())
+            dist.init_process_group(backend)
             try:
                 _ddp_worker(int(os.environ["RANK"]), world, cfg)
             finally:

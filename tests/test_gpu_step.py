@@ -150,12 +150,15 @@ def test_overlapped_matching_equals_sequential_step(matching):
     N, B = 32, 48
     host = [synthetic_batch("enzymes", B, N, "deg", seed=s) for s in (3, 4)]
     runs = []
-    for overlap, pipeline in ((False, False), (True, False), (True, True)):
+    # the last schedule gets no probe at all (tries = 0): the side streams are then whatever the
+    # pool hands out, possibly sharing a hardware queue with the current stream
+    for overlap, pipeline, tries in ((False, False, 4), (True, False, 4), (True, True, 4), (True, True, 0)):
         torch.manual_seed(42)
         model = GraphVAE(1, 64, 32, N, matching=matching)
         model.precompute_dataset_rho(host)
         model = model.to(DEV).train()
-        step = TrainStep(model, 1e-2, 1e-4, 5.0, overlap_matching=overlap, pipeline=pipeline)
+        step = TrainStep(model, 1e-2, 1e-4, 5.0, overlap_matching=overlap, pipeline=pipeline,
+                         probe_tries=tries)
         assert step.overlap_matching == overlap and step.pipeline == pipeline
         gen = torch.Generator(device="cpu").manual_seed(9)
         outs, perms, iters = [], [], []
@@ -170,6 +173,11 @@ def test_overlapped_matching_equals_sequential_step(matching):
                 iters.append(model.last_mpm_iterations().cpu())
         loss_sum = step.pop_loss_sum().cpu()
         assert float(step.loss_sum) == 0.0
+        if overlap:
+            from graphvae.train.train_ddp import concurrent_stream
+            assert step._side.priority == 0 and (step._tail is None or step._tail.priority == 0)
+            if tries == 0:
+                assert concurrent_stream.last_probe == (0, False)
         model._engine.check_matching()
         runs.append((torch.stack(outs), torch.stack(perms), torch.stack(iters), loss_sum,
                      model.flat_parameters().detach().cpu().clone(), model.bn_state().cpu().clone()))
@@ -332,3 +340,72 @@ def test_forward_requires_rho_and_gpu():
     model.rho_global = 0.5
     with pytest.raises(GvaeHipError):
         model(hb)                       # CPU model + CPU batch: no fallback
+
+
+def test_backward_accumulates_over_micro_batches(golden_dir):
+    """Two forward/backward passes without zeroing: .grad holds g1 + g2 (the autograd bridge
+    hands out fresh tensors; views of one persistent buffer would give 2 * g2)."""
+    G = load_g5(golden_dir / "g5_forward_rand_deg.npz")
+    model, batch, eps = _model_and_batch(G)
+    model.train()
+    singles = []
+    for scale in (1.0, 3.0):
+        model.zero_grad(set_to_none=True)
+        out = model.forward_with_eps(batch, eps)
+        (scale * out["loss"]).backward()
+        singles.append([p.grad.detach().clone() for p in model._named_param_list()])
+    model.zero_grad(set_to_none=True)
+    for scale in (1.0, 3.0):
+        out = model.forward_with_eps(batch, eps)
+        (scale * out["loss"]).backward()
+    for p, g1, g2 in zip(model._named_param_list(), *singles):
+        assert torch.equal(p.grad, g1 + g2)
+    # zero_grad(set_to_none=False) keeps the tensors: the next backward must not see stale values
+    model.zero_grad(set_to_none=False)
+    out = model.forward_with_eps(batch, eps)
+    out["loss"].backward()
+    for p, g1 in zip(model._named_param_list(), singles[0]):
+        assert torch.equal(p.grad, g1)
+
+
+def test_eval_mode_backward_vs_cpu_restatement():
+    """After model.eval() the forward normalises with the running statistics, which are
+    constants of the input: the BatchNorm backward is then dY = dpre * invstd * gamma (no batch
+    mean / variance terms).  Gradients against autograd of the CPU restatement in eval mode."""
+    from graphvae.data import synthetic_batch
+    from graphvae.models import GraphVAE
+    N, B = 16, 6
+    hb = synthetic_batch("enzymes", B, N, "deg", seed=8)
+    torch.manual_seed(12)
+    model = GraphVAE(1, 32, 16, N)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("bias") or n_.startswith("bn"):
+                p.add_(0.1 * torch.randn(p.shape))
+        for bn in (model.bn1, model.bn2):                 # non-trivial running statistics
+            bn.running_mean.add_(0.2 * torch.randn(32))
+            bn.running_var.mul_(1.0 + 0.5 * torch.rand(32))
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.precompute_dataset_rho([hb])
+    state0["pos_weight_global"] = model.pos_weight_global.detach().clone()
+    eps = torch.randn(B, 16)
+    model = model.to(DEV).eval()
+    out = model.forward_with_eps(hb.to(DEV), eps.to(DEV))
+    out["loss"].backward()
+    st = R.make_trainable(state0)
+    graphs = R.graphs_from_arrays(hb.x, hb.adj_dense, hb.n_x, hb.num_real_nodes)
+    res = R.forward_batch(st, graphs, [eps[g:g + 1] for g in range(B)], train=False)
+    res.loss.backward()
+    for k in ("rec", "kl", "loss"):
+        assert rel_err(out[k].item(), getattr(res, k).item()) < TOL, k
+    for n_, p in model.named_parameters():
+        ref = st[n_].grad.numpy()
+        got = p.grad.detach().cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-6), n_
+    # and the training-mode gradients of the same batch differ (the flag is not a no-op)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    out = model.forward_with_eps(hb.to(DEV), eps.to(DEV))
+    out["loss"].backward()
+    g_train = model.conv1.lin.weight.grad.cpu().numpy()
+    assert np.abs(g_train - st["conv1.lin.weight"].grad.numpy()).max() > 1e-3 * np.abs(g_train).max()
