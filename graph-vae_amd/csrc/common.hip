@@ -32,7 +32,7 @@ static std::vector<EventPair> g_events;   // pairs recorded since the last reset
 static std::vector<EventPair> g_pool;     // created events kept for reuse (creation is slow)
 
 ProfileScope::ProfileScope(int fam, hipStream_t s) : family(fam), stream(s), slot(-1) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || fam < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   EventPair p{fam, nullptr, nullptr};
   if (!g_pool.empty()) {

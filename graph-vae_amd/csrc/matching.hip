@@ -6,6 +6,8 @@
 #include "gvae_lsap.h"
 #include "gvae_common.h"
 
+#include <mutex>
+
 namespace gvae {
 
 // ---------------------------------------------------------------------------
@@ -1359,7 +1361,7 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
 static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
                              int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
                              float tol, int early_stop, int32_t *d_iters_done, void *d_ws,
-                             bool first_iter_done, void *stream) {
+                             bool first_iter_done, void *stream, bool profiled = true) {
   GVAE_REQUIRE(d_S && d_S_off && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "mpm_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
@@ -1437,7 +1439,8 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
                      s_layout, d_iters_done, first_stop, iters);
   {
-    ProfileScope ps(F_MPM_ITER, s);
+    // (the event profiler creates events on first use: not for callers that must not allocate)
+    ProfileScope ps(profiled ? F_MPM_ITER : -1, s);
     hipLaunchKernelGGL(mpm_stream_kernel, dim3(blocks), dim3(nt), lds, s, d_S, d_S_off, d_R, r_max,
                        d_X, ldx, strideX, Xnew, strideXnew, tol, early_stop, iters, s_layout, q,
                        d_iters_done);
@@ -1452,6 +1455,57 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
   return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
                            early_stop, d_iters_done, d_ws, false, stream);
+}
+
+// ---------------------------------------------------------------------------
+// The same matching for callers that cannot allocate device memory: the workspace of
+// gvae_mpm_stream (next-X buffer, queue words, ring slots, arrival counters) lives in a
+// file-scope device array instead of coming in as an argument.  Host code never passes the
+// array's name to a kernel or to a memset (on the host that name is a stand-in, not a device
+// address): the address is taken once per device with hipGetSymbolAddress and kept.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[GVAE_STATIC_SCRATCH_BYTES];
+
+#define GVAE_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[GVAE_MAX_DEVICES];   // device address of `scratch` on each device
+
+// address of this device's copy of `scratch` (every GPU holds its own, at its own address)
+static int scratch_of_current_device(void **out) {
+  int dev = -1;
+  GVAE_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GVAE_MAX_DEVICES, GVAE_ELAUNCH,
+               "mpm_stream_static: cannot identify the current device");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    GVAE_REQUIRE(e == hipSuccess && p, GVAE_ELAUNCH,
+                 "mpm_stream_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                 hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GVAE_OK;
+}
+
+int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                           int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                           float tol, int early_stop, int32_t *d_iters_done, void *stream) {
+  GVAE_REQUIRE(n_graphs >= 0 && ldx > 0, GVAE_EINVAL, "mpm_stream_static: bad sizes (n_graphs=%d ldx=%d)",
+               n_graphs, ldx);
+  const int64_t need = gvae_mpm_stream_ws_bytes(n_graphs, ldx);
+  GVAE_REQUIRE(need <= (int64_t)GVAE_STATIC_SCRATCH_BYTES, GVAE_ELIMIT,
+               "mpm_stream_static: %d graphs with ldx=%d need %lld bytes of scratch, the built-in "
+               "buffer holds %d (use gvae_mpm_stream with a workspace of your own)",
+               n_graphs, ldx, (long long)need, GVAE_STATIC_SCRATCH_BYTES);
+  void *ws = nullptr;
+  const int rc = scratch_of_current_device(&ws);
+  if (rc) return rc;
+  // the launch clears what must start at zero (queue words and ring slots by memset, arrival
+  // counters and iteration counts in the queue's set-up kernel); the rest of the buffer is
+  // written before it is read
+  return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
+                           early_stop, d_iters_done, ws, false, stream, /*profiled=*/false);
 }
 
 int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,

@@ -51,6 +51,8 @@ def lib() -> ctypes.CDLL:
         L.gvae_mpm_stream.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p,
                                       c_void_p]
+        L.gvae_mpm_stream_static.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                             c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p]
         L.gvae_match_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                         c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]
@@ -182,6 +184,24 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
                                  X.data_ptr(), N, N * N, iters, tol, int(early_stop),
                                  done.data_ptr(), ws.data_ptr(), _stream()))
     return done
+
+
+STATIC_SCRATCH_BYTES = 2 << 20
+
+
+def mpm_stream_static(S, S_off, R, r_max: int, X, done, iters: int = 50, tol: float = 1e-4,
+                      early_stop: bool = True, layout: int = S_DENSE) -> None:
+    """gvae_mpm_stream_static: as `mpm_stream`, with the library's built-in scratch buffer (no
+    workspace, nothing allocated by the call: `done` (G,) int32 comes from the caller too).
+    Raises for batches whose workspace would exceed STATIC_SCRATCH_BYTES."""
+    _dev(S, torch.float32), _dev(S_off, torch.int64), _dev(R, torch.int32), _dev(X, torch.float32)
+    _dev(done, torch.int32)
+    G, N, _ = X.shape
+    if done.numel() != G:
+        raise GvaeHipError("mpm_stream_static: `done` must have one entry per graph")
+    _check(lib().gvae_mpm_stream_static(S.data_ptr(), S_off.data_ptr(), layout, R.data_ptr(), G, r_max,
+                                        X.data_ptr(), N, N * N, iters, tol, int(early_stop),
+                                        done.data_ptr(), _stream()))
 
 
 def match_stream(A, P, NS, R, R_host, X, iters: int = 50, tol: float = 1e-4, early_stop: bool = True,

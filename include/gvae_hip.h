@@ -91,6 +91,20 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                     int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
 
+/* gvae_mpm_stream without the workspace argument, for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  The workspace is a built-in device array of
+ * GVAE_STATIC_SCRATCH_BYTES bytes per GPU (held from the first call on that GPU until the
+ * process ends); the call allocates and frees nothing and records no profiler events.
+ * Accepted sizes: gvae_mpm_stream_ws_bytes(n_graphs, ldx) <= GVAE_STATIC_SCRATCH_BYTES (e.g. 340
+ * graphs at ldx 32, 100 at ldx 64, 28 at ldx 128); larger ones fail with GVAE_ELIMIT.  Every call
+ * on a GPU shares that GPU's array: calls on one GPU must not overlap (two streams, two
+ * threads), they would race on the queue.  Same X and iteration counts as gvae_mpm_stream. */
+#define GVAE_STATIC_SCRATCH_BYTES (2 << 20)
+int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
+                           int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
+                           float tol, int early_stop, int32_t *d_iters_done, void *stream);
+
 /* gvae_edge_sim followed by gvae_mpm_stream from the uniform start X0 = 1/R of
  * graphvae/models/model.py:317, in one call (what the step's streamed matching uses).  The
  * tensor is written as by gvae_edge_sim; the FIRST iteration is computed without reading it
