@@ -146,13 +146,20 @@ def vec_to_adj(vec, N):
 
 def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: float = 0.1,
                   mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
-                  no_grad_matching: bool = False, legacy_mask: bool = False):
+                  no_grad_matching: bool = False, legacy_mask: bool = False,
+                  sfree_matching: bool = False, skip_matching: bool = False):
     """One graph through reference model.py:288-366.  `g` has x (n_x,F), adj_dense (N,N),
     num_real_nodes.  Mutates the BN running statistics in `st` when train.
     `legacy_mask` selects the older loss `forward_old` (model.py:403-408,425-427): the logits
     of padded nodes are overwritten with -10 before the node loss, so they contribute the
     constant softplus(-10) each and receive no gradient; everything else is unchanged (the
-    R x R block handed to the matching is not touched by the overwrite)."""
+    R x R block handed to the matching is not touched by the overwrite).
+    `sfree_matching`: run the MPM through the C oracle's S-free form (oracle/gvae_oracle.c,
+    bit-equal to the materialised form, tests/test_oracle_golden.py) without autograd: what
+    makes graphs of 64-128 nodes checkable in seconds (S would be 64 MiB - 1 GiB each).
+    `skip_matching`: identity permutation (for float64 yardsticks at sizes where S does not fit:
+    prediction and truth are gathered through the same permutation, model.py:325-326, so the
+    loss and its gradients do not depend on it beyond rounding)."""
     N = g.adj_dense.size(0)
     R = int(g.num_real_nodes)
     A_gt = g.adj_dense
@@ -188,7 +195,14 @@ def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: floa
         X0 = torch.full((R, R), 1 / R)
         X, done = mpm(X0, S, mpm_iters, tol, early_stop)
         return X, done
-    if no_grad_matching:
+    if skip_matching:
+        X, done = torch.eye(R, dtype=A_hat.dtype), 0
+    elif sfree_matching:
+        from . import matching as ora
+        Xn, done = ora.mpm_sfree(A_gt[:R, :R].numpy(), A_hat.sigmoid()[:R, :R].detach().numpy(),
+                                 iters=mpm_iters, tol=tol, early_stop=early_stop)
+        X = torch.from_numpy(Xn)
+    elif no_grad_matching:
         with torch.no_grad():
             X, done = matching()
     else:

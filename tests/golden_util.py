@@ -43,6 +43,74 @@ def load_g10(golden_dir):
     return G, SimpleNamespace(out=out, grads=grads, perms=perms)
 
 
+PARAM_SHAPES = lambda F, H, Z, N: {  # noqa: E731  (reference model.py:71-89, named_parameters order)
+    "conv1.bias": (H,), "conv1.lin.weight": (H, F), "bn1.weight": (H,), "bn1.bias": (H,),
+    "conv2.bias": (H,), "conv2.lin.weight": (H, H), "bn2.weight": (H,), "bn2.bias": (H,),
+    "mu.weight": (Z, H), "mu.bias": (Z,), "logvar.weight": (Z, H), "logvar.bias": (Z,),
+    "dec_edge.0.weight": (H, Z), "dec_edge.0.bias": (H,),
+    "dec_edge.2.weight": (N * (N - 1) // 2, H), "dec_edge.2.bias": (N * (N - 1) // 2,),
+    "dec_node.0.weight": (H, Z), "dec_node.0.bias": (H,),
+    "dec_node.2.weight": (N, H), "dec_node.2.bias": (N,)}
+
+
+def seeded_state(F: int, H: int, Z: int, N: int, seed: int) -> dict:
+    """A full state_dict as a pure function of (dims, seed): Xavier-uniform (gain sqrt 2) weight
+    matrices, biases and BatchNorm affine terms perturbed by 0.1 * normal so that every gradient
+    path is exercised, fresh running statistics.  Fixtures generated from large models store
+    the seed instead of megabytes of weights; generator and tests both call this."""
+    rng = np.random.default_rng(seed)
+    st = {}
+    for name, shp in PARAM_SHAPES(F, H, Z, N).items():
+        if len(shp) == 2:
+            b = np.sqrt(2.0) * np.sqrt(6.0 / (shp[0] + shp[1]))
+            a = rng.uniform(-b, b, shp)
+        elif name in ("bn1.weight", "bn2.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        else:
+            a = 0.1 * rng.standard_normal(shp)
+        st[name] = torch.from_numpy(a.astype(np.float32))
+    for b in ("bn1", "bn2"):
+        st[f"{b}.running_mean"] = torch.zeros(H)
+        st[f"{b}.running_var"] = torch.ones(H)
+        st[f"{b}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    st["pos_weight_global"] = torch.tensor(1.0)
+    return st
+
+
+def graph_from_block(block: np.ndarray, N: int):
+    """Graph record of the reference's data contract (train_ddp.py:67-112, `deg` features) from
+    the R x R 0/1 adjacency block without self loops."""
+    R = block.shape[0]
+    adj = torch.zeros(N, N)
+    adj[:R, :R] = torch.from_numpy(block.astype(np.float32))
+    adj[torch.arange(R), torch.arange(R)] = 1.0
+    x = torch.zeros(N, 1)
+    x[:R, 0] = torch.from_numpy(block.sum(1).astype(np.float32))
+    src, dst = np.nonzero(block)
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    return SimpleNamespace(x=x, edge_index=ei, adj_dense=adj, num_real_nodes=R)
+
+
+def load_g11(path):
+    """g11_forward_N*.npz: the reference's forward/backward at max_nodes 64 / 126 / 128 with the
+    trainer's default widths, on ENZYMES-shaped graphs small enough for the reference's CPU path."""
+    g = np.load(path, allow_pickle=False)
+    n, N, H, Z, seed = (int(g[k]) for k in ("n_graphs", "N", "H", "Z", "seed"))
+    graphs = [graph_from_block(g[f"g{i}/block"], N) for i in range(n)]
+    state0 = seeded_state(1, H, Z, N, seed)
+    state0["pos_weight_global"] = torch.tensor(float(g["pos_weight"]))
+    grads = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    return SimpleNamespace(
+        graphs=graphs, eps=[torch.from_numpy(g[f"g{i}/eps"]) for i in range(n)],
+        perms=[g[f"g{i}/perm"] for i in range(n)], P=[g[f"g{i}/P"] for i in range(n)],
+        X=[g[f"g{i}/X"] for i in range(n)], iters=[int(g[f"g{i}/iters"]) for i in range(n)],
+        state0=state0, grads=grads,
+        state1={k[len("state1/"):]: g[k] for k in g.files if k.startswith("state1/")},
+        out={k[len("out/"):]: g[k] for k in g.files if k.startswith("out/")},
+        out_eval={k[len("out_eval/"):]: g[k] for k in g.files if k.startswith("out_eval/")},
+        dims=dict(N=N, H=H, Z=Z, in_dim=1), rho=float(g["rho"]))
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
@@ -51,7 +119,7 @@ def rel_err(a, b):
 ZERO_GRAD_PARAMS = ("conv1.bias", "conv2.bias")
 
 
-def truth64(G, **kw):
+def truth64(G, want_res: bool = False, **kw):
     """Loss and gradients of the golden case recomputed in float64 by the CPU
     restatement: the yardstick for how far the fp32 reference itself is from the exact
     answer (BatchNorm over a handful of near-identical rows is ill-conditioned)."""
@@ -65,7 +133,8 @@ def truth64(G, **kw):
                                   num_real_nodes=g.num_real_nodes) for g in G.graphs]
         res = R.forward_batch(st, graphs, [e.double() for e in G.eps], train=True, **kw)
         res.loss.backward()
-        return {n: st[n].grad.numpy().copy() for n in R.PARAM_NAMES}
+        grads = {n: st[n].grad.numpy().copy() for n in R.PARAM_NAMES}
+        return (grads, res) if want_res else grads
     finally:
         torch.set_default_dtype(old)
 

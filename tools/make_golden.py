@@ -501,6 +501,78 @@ def gen_forward_old(ref, out: Path):
           f"diff {d:+.3e}) kl={res['kl'].item():.6f}")
 
 
+def gen_forward_large(ref, out: Path):
+    """G11: forward + backward of the imported reference at the max_nodes of the larger BASELINE
+    configurations (64, 126, 128) with the trainer's default widths (hid 128, z 64), on
+    ENZYMES-shaped graphs of at most 48 real nodes (what the reference's CPU path can hold: it
+    keeps every MPM iteration's R^4 product for autograd).  Weights come from
+    tests/golden_util.seeded_state (a function of the stored seed); gradients of padded pairs
+    are exact zeros, so the large tensors compress."""
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+    from golden_util import graph_from_block, seeded_state
+    H, Z = 128, 64
+    sizes = {64: [48, 40, 33, 21, 12, 30, 5, 37], 126: [40, 26, 38, 9, 31, 17, 2, 35],
+             128: [39, 3, 28, 36, 14, 40, 22, 8]}
+    for N, Rs in sizes.items():
+        seed = 9000 + N
+        rng = np.random.default_rng(seed)
+        blocks = []
+        for R in Rs:
+            p = min(1.0, 3.8 / max(R - 1, 1))
+            up = np.triu((rng.random((R, R)) < p).astype(np.uint8), 1)
+            blocks.append(up + up.T)
+        graphs = [graph_from_block(b, N) for b in blocks]
+        for g in graphs:
+            g.num_real_nodes = torch.tensor(g.num_real_nodes, dtype=torch.long)
+        model = ref.GraphVAE(1, H, Z, N)
+        state0 = seeded_state(1, H, Z, N, seed)
+        pos_e = sum(float(np.triu(b, 1).sum()) for b in blocks)
+        pairs = sum(R * (R - 1) / 2 for R in Rs)
+        rho = pos_e / (pairs + 1e-8)
+        pw = float(np.clip((1 - rho) / (rho + 1e-8), 1.0, 20.0))
+        state0["pos_weight_global"] = torch.tensor(pw)
+        model.load_state_dict(state0)
+        model.rho_global = rho
+        gen = torch.Generator().manual_seed(seed)
+        eps = [torch.randn(1, Z, generator=gen) for _ in graphs]
+        iters = []
+        orig_mpm = model._mpm
+
+        def counting_mpm(X0, S, *a, **k):
+            with IterSpy() as spy:
+                X = orig_mpm(X0, S, *a, **k)
+            iters.append(spy.count)
+            return X
+
+        model._mpm = counting_mpm
+        res, perms = run_reference_step(ref, model, graphs, eps, train=True)
+        res["loss"].backward()
+        store = {"meta": np.array(f"enzymes-shaped/deg max_nodes={N}; encoder parity unpinned (PyG GCNConv restated)"),
+                 "N": np.int64(N), "H": np.int64(H), "Z": np.int64(Z), "seed": np.int64(seed),
+                 "rho": np.float64(rho), "pos_weight": np.float64(pw), "n_graphs": np.int64(len(graphs))}
+        for i, b in enumerate(blocks):
+            store[f"g{i}/block"] = b
+            store[f"g{i}/eps"] = eps[i].numpy()
+            store[f"g{i}/perm"] = perms[i]
+            store[f"g{i}/P"] = res["P"][i]
+            store[f"g{i}/X"] = res["X"][i]
+            store[f"g{i}/iters"] = np.int64(iters[i])
+        for k in ("rec", "kl", "loss", "max_logit", "logvar_max", "rec_i", "kl_i"):
+            store[f"out/{k}"] = res[k].detach().numpy()
+        for n_, p in model.named_parameters():
+            store[f"grad/{n_}"] = p.grad.numpy().copy()
+        for k, v in model.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                store[f"state1/{k}"] = v.numpy().copy()
+        with torch.no_grad():
+            res_e, _ = run_reference_step(ref, model, graphs, eps, train=False)
+        for k in ("rec", "kl", "loss"):
+            store[f"out_eval/{k}"] = res_e[k].numpy()
+        np.savez_compressed(out / f"g11_forward_N{N}.npz", **store)
+        print(f"G11 N={N}: loss={res['loss'].item():.6f} rec={res['rec'].item():.6f} kl={res['kl'].item():.6f} "
+              f"iters={iters[:len(graphs)]}")
+
+
 def gen_rho(ref, out: Path):
     """precompute_dataset_rho (reference model.py:99-118) on the grid graphs."""
     nxg, N = graphs_for_forward("grid")
@@ -578,7 +650,7 @@ def gen_sampler(ref, out: Path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(Path(__file__).resolve().parents[1] / "tests" / "golden"))
-    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler | forward_old)")
+    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler | forward_old | forward_large)")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
@@ -590,12 +662,16 @@ def main():
     if args.only == "forward_old":
         gen_forward_old(ref, out)
         return
+    if args.only == "forward_large":
+        gen_forward_large(ref, out)
+        return
     gen_forward_test(ref, out)
     gen_reduction_orders(out)
     gen_lsap(out)
     gen_rho(ref, out)
     gen_forward(ref, out)
     gen_forward_old(ref, out)
+    gen_forward_large(ref, out)
     gen_matching(ref, out)
     gen_sampler(ref, out)
 
