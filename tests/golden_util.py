@@ -139,11 +139,22 @@ def truth64(G, want_res: bool = False, **kw):
         torch.set_default_dtype(old)
 
 
-def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e-5):
+# conv1.lin.weight is an (H, F) sum over every node row of the batch with heavy cancellation (for
+# `deg` features the terms are degree-weighted): two fp32 evaluations of it differ by several
+# times the distance of either from the float64 value (measured: two CPU evaluations, or CPU and
+# GPU, land on opposite sides of it).
+CANCELLATION_PARAMS = ("conv1.lin.weight",)
+
+
+def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e-5,
+                slack_factor: float = 2.0):
     """Each gradient tensor within `tol` relative (to its largest entry) of the
-    reference's, plus, when `truth` (float64 recomputation) is given, four times the
-    reference's own distance from it -- a result cannot be asked to sit closer to the
-    fp32 reference than that reference sits to the exact value.  The two GCN biases feed
+    reference's, plus, when `truth` (float64 recomputation) is given, `slack_factor` times the
+    reference's own distance from it: two fp32 evaluations that are equally accurate sit up to
+    twice that distance apart (opposite sides of the exact value), so 2 is the smallest factor
+    that does not ask the candidate to be MORE accurate than the reference (4 for the
+    cancellation-dominated tensor above).  Prints, per tensor, the distances of both from the
+    float64 value (pytest -s shows them).  The two GCN biases feed
     straight into a training-mode BatchNorm, which cancels any per-column constant: their
     true gradient is zero and the reference holds only rounding noise there, so those are
     only required to be noise (<= 20*tol of the model-wide gradient scale; the reference's
@@ -155,8 +166,13 @@ def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e
         if name in ZERO_GRAD_PARAMS:
             assert np.abs(g).max() <= 20 * tol * gmax and np.abs(r).max() <= 20 * tol * gmax, name
             continue
-        slack = 4.0 * float(np.abs(r - truth[name]).max()) if truth is not None else 0.0
+        k = 2.0 * slack_factor if name in CANCELLATION_PARAMS else slack_factor
+        slack = k * float(np.abs(r - truth[name]).max()) if truth is not None else 0.0
         err = float(np.abs(g - r).max())
+        if truth is not None:
+            m = max(float(np.abs(truth[name]).max()), 1e-30)
+            print(f"  grad {name:20s} |got-ref| {err / m:.2e}  |got-f64| {np.abs(g - truth[name]).max() / m:.2e}  "
+                  f"|ref-f64| {np.abs(r - truth[name]).max() / m:.2e}")
         assert err <= tol * max(np.abs(r).max(), 1e-30) + slack, (name, err, float(np.abs(r).max()), slack)
 
 

@@ -22,13 +22,16 @@ TOL = 1e-5
 # formula differ by ~4e-5 of its scale (the reference sits 6e-6 from the float64 value).
 LEGACY_GRAD_TOL = 5e-5
 DEV = "cuda:0"
-# Gradient tolerance per golden case.  grid/deg contains the 2x2 grid graph, whose four
-# real nodes are all equivalent: a layer-2 BatchNorm column there has variance 1.3e-5 (about
-# the BatchNorm eps), so its normalisation multiplies the fp32 rounding of the preceding
-# GEMM by ~200 and the pooled vector is only determined to ~5e-5 in fp32 (the reference's
-# own gradients sit 4e-5..3e-4 from their float64 values on that case, the GPU's 3e-4..6e-4).
-# Losses, probabilities and permutations keep the 1e-5 bar on every case.
-GRAD_TOL = {"grid_deg": 2e-3}
+# Gradient tolerance per golden case (on top of it: 1 x the reference's own distance from the
+# float64 value, golden_util.check_grads).  grid/deg contains the 2x2 grid graph, whose four
+# real nodes are equivalent and whose five padded rows form a second cluster 3.6e-3 away: a
+# layer-2 BatchNorm column there has variance 1.3e-5 (about the BatchNorm eps), the
+# normalisation divides fp32 values that agree in their first three digits, and the pooled
+# vector is only determined to ~5e-5 in fp32 whatever the summation order (the reference's own
+# gradients sit 4e-5..3e-4 from their float64 values on that case, the GPU's 3e-4..6e-4; the
+# inputs of that BatchNorm are within 3e-7 of float64 on the GPU).  Losses, probabilities and
+# permutations keep the 1e-5 bar on every case.
+GRAD_TOL = {"grid_deg": 7e-4}
 
 
 def _model_and_batch(G, matching="auto"):
