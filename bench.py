@@ -188,6 +188,8 @@ def main():
     def note(msg):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
+    if os.environ.get("GVAE_HANDOFF_MB"):            # tuning: tail hand-off threshold of the streamed matching
+        _hip.set_stream_handoff_bytes(int(float(os.environ["GVAE_HANDOFF_MB"]) * (1 << 20)))
     results = {}
     roof = None
     host_batches = None
@@ -217,27 +219,43 @@ def main():
             # launch of the streaming MPM kernel (on the stream it is launched on)
             _hip.profile_reset()
             _hip.profile_enable(True)
+            slots = range(len(eng._slots))
+
+            def stream_counters(reset):
+                tot_b = tot_n = 0
+                cur = eng._cur
+                for k in slots:
+                    eng.use_slot(k)
+                    if eng._fwd_batch is not None:
+                        b_, n_ = eng.stream_stats(reset=reset)
+                        tot_b, tot_n = tot_b + b_, tot_n + n_
+                eng.use_slot(cur)
+                return tot_b, tot_n
+
+            step_fn.wait()
+            torch.cuda.synchronize()
+            stream_counters(reset=True)
             timed_steps(step_fn, batches, args.steps, 0, world, device, iters_acc, eng)
             _hip.profile_enable(False)
             ms_iter, n_iter = _hip.profile_read("mpm_stream_iter")
             ms_es, n_es = _hip.profile_read("edge_sim")
+            ms_tail, n_tail = _hip.profile_read("mpm_fused")
             _hip.profile_reset()
+            # what the streaming kernel executed, counted on the device by the kernel itself:
+            # sum over its graph-iterations of 4 R^4 + 12 R^2 bytes
+            dev_bytes, dev_gi = stream_counters(reset=False)
             # algorithmic bytes of the streaming MPM kernel: every (graph, iteration) it executes
             # reads S once (4 R^4) plus X, X_new and the node block (12 R^2).  The first iteration
             # of a graph is not among them: the step computes it from row maxima of S without
             # reading the tensor back (gvae_match_stream), so the kernel streams iterations 2..k.
             r = np.array([rr for s in range(args.steps) for rr in batches[s % len(batches)].r_host],
                          dtype=np.float64)
+            # Neither are the iterations of the latency-bound tail, which the S-free kernel takes
+            # over (gvae_set_stream_handoff_bytes): the kernel counts what it streams.
             first = 1.0 if args.mpm_iters >= 1 else 0.0
-            if early_stop:
-                # iterations differ per graph: use the device-side total and the batch's mean
-                # bytes per graph-iteration (exact for uniform-size workloads)
-                bytes_per_gi = float(np.mean(4.0 * r ** 4 + 12.0 * r ** 2))
-                streamed_gi = float(iters_acc.item()) - first * len(r)
-                alg_bytes = streamed_gi * bytes_per_gi
-            else:
-                streamed_gi = float(len(r)) * (args.mpm_iters - first)
-                alg_bytes = float(np.sum(4.0 * r ** 4 + 12.0 * r ** 2)) * (args.mpm_iters - first)
+            streamed_gi, alg_bytes = float(dev_gi), float(dev_bytes)
+            if not early_stop:      # cross-check of the device counters where the count is known
+                assert streamed_gi == float(len(r)) * (args.mpm_iters - first), (streamed_gi, len(r))
             achieved = alg_bytes / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else 0.0
             # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as gfx950 needs,
             # + WRITE_SIZE), measured with rocprofv3 on this workload's kernel and stored per
@@ -257,6 +275,8 @@ def main():
                     "launches": int(n_iter), "avg_launch_ms": ms_iter / max(1, n_iter),
                     "alg_bytes_per_launch": alg_bytes / max(1, n_iter),
                     "mean_mpm_iters_per_graph": float(iters_acc.item()) / (args.steps * per_gpu),
+                    "streamed_iters_per_graph": streamed_gi / (args.steps * per_gpu),
+                    "tail_sfree_ms_per_step": ms_tail / max(1, args.steps),
                     "edge_sim_GBps": (float(np.sum(4.0 * r ** 4)) / (ms_es * 1e-3) / 1e9) if ms_es > 0 else None}
         results[leg] = {"value": world * per_gpu * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
                         "per_gpu_batch": per_gpu}

@@ -25,3 +25,8 @@ for b in batches:
     print(f"sizes: max {int(r.max())}, >64: {(r > 64).sum()}, mean {r.mean():.1f}; bytes {total/1e9:.2f} GB -> "
           f"{total/7.0e12*1e3:.2f} ms at 7 TB/s; longest chain: graph of {int(r[k])} nodes, {int(it[k])} iterations "
           f"-> {chain[k]*1e3:.2f} ms; top chains (ms): {np.sort(chain)[-4:][::-1].round(4)*1e3}")
+    order = np.argsort(-r)
+    print("  sizes (desc):", r[order][:20].astype(int).tolist())
+    print("  iterations  :", it[order][:20].astype(int).tolist())
+    alive_bytes = [float(per_iter[it > k].sum()) for k in range(50)]
+    print("  bytes per round (MB) while graphs drop out:", [round(x / 1e6) for x in alive_bytes[::4]])

@@ -113,7 +113,8 @@ __device__ __forceinline__ double pick_f64(const double (&a)[NCH], int idx) {
 // list order, else the first one in list order" becomes one integer maximum over the keys
 //   unassigned: 0x10000 + pos      assigned: 0xFFFF - pos      (list positions are unique)
 template <int NCH, int LANES = 64>
-__device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, int (&col4row)[NCH]) {
+__device__ __forceinline__ int lsap_solve(const float *cost, int n, int ld, int lane,
+                                          int (&col4row)[NCH]) {
   double u[NCH], v[NCH], spc[NCH];
   int path[NCH], row4col[NCH], pos[NCH], ccol[NCH];
   // scanned rows / columns of the current augmentation as wave-uniform bit masks
@@ -141,7 +142,7 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
       if (NCH == 1 || i < 64) sr[0] |= 1ull << (i & 63);
       else sr[NCH - 1] |= 1ull << (i & 63);
       const double ui = pick_f64<NCH>(u, i);
-      const float *crow = cost + i * n;
+      const float *crow = cost + i * ld;
       double lowest = INFINITY;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -227,15 +228,16 @@ __device__ __forceinline__ int lsap_solve(const float *cost, int n, int lane, in
 }
 
 // Whole assignment of one graph by the calling wavefront: cost = -X, X as n x n floats in LDS
-// (row stride n).  Writes perm_full (reference model.py:321-323: perm[col4row[i]] = i, identity
+// (row stride ld).  Writes perm_full (reference model.py:321-323: perm[col4row[i]] = i, identity
 // beyond n and on failure) and the status word (0 ok, 1 NaN / +inf in X or infeasible).
 // `lane` = 0..63; every lane of the wave must call.
-__device__ __forceinline__ void lsap_wave(const float *cost, int n, int lane, int64_t *pg, int n_perm,
-                                          int32_t *status) {
+__device__ __forceinline__ void lsap_wave(const float *cost, int n, int ld, int lane, int64_t *pg,
+                                          int n_perm, int32_t *status) {
   for (int k = lane; k < n_perm; k += 64) pg[k] = k;
   int bad = 0;
   for (int e = lane; e < n * n; e += 64) {
-    const float x = cost[e];
+    const int r = e / n;
+    const float x = cost[r * ld + (e - r * n)];
     bad |= (x != x) || (x == INFINITY);  // cost = -x: NaN or -inf is invalid
   }
   bad = wave_max_i32(bad);
@@ -246,13 +248,13 @@ __device__ __forceinline__ void lsap_wave(const float *cost, int n, int lane, in
   int fail;
   if (n <= 64) {
     int col4row[1];
-    if (n <= 16) fail = lsap_solve<1, 16>(cost, n, lane, col4row);
-    else if (n <= 32) fail = lsap_solve<1, 32>(cost, n, lane, col4row);
-    else fail = lsap_solve<1>(cost, n, lane, col4row);
+    if (n <= 16) fail = lsap_solve<1, 16>(cost, n, ld, lane, col4row);
+    else if (n <= 32) fail = lsap_solve<1, 32>(cost, n, ld, lane, col4row);
+    else fail = lsap_solve<1>(cost, n, ld, lane, col4row);
     if (!fail && lane < n) pg[col4row[0]] = lane;            // perm[col4row[i]] = i
   } else {
     int col4row[2];
-    fail = lsap_solve<2>(cost, n, lane, col4row);
+    fail = lsap_solve<2>(cost, n, ld, lane, col4row);
     if (!fail) {
       pg[col4row[0]] = lane;
       if (64 + lane < n) pg[col4row[1]] = 64 + lane;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ X, i
     cost[e] = Xg[(int64_t)r * ldx + c];
   }
   __syncthreads();
-  lsap_wave(cost, n, lane, pg, n_perm, status + g);
+  lsap_wave(cost, n, n, lane, pg, n_perm, status + g);
 }
 
 }  // namespace gvae

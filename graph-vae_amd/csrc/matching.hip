@@ -501,16 +501,33 @@ __host__ __device__ __forceinline__ unsigned mpm_shape_item(int g, int p, int co
 
 struct MpmQueue {
   unsigned long long *slots;  // [cap]
-  int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [96] error
+  int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [65] their slab KiB  [96] error
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
+  // Hand-off of the latency-bound tail (gvae_match_stream only; handoff == nullptr: never).  Once
+  // the slabs of all graphs still iterating add up to less than handoff_kb KiB, one pass over
+  // them takes the device less time than the chain of dependent steps of one iteration (ticket,
+  // X, slab pieces, hand-off to the last arriver, normalisation, push: about 19 us), so the
+  // batch is bound by that latency, not by HBM.  A graph of at most handoff_rmax nodes that
+  // finishes an iteration in that state leaves the queue with handoff[g] = 1, and the S-free
+  // kernel (same recurrence, same bits, no HBM traffic in its loop) runs its remaining
+  // iterations after this launch.
+  int32_t *handoff;           // [n_graphs] out
+  const int32_t *sfree_ok;    // [n_graphs] bit 1: the S-free form is valid for the graph
+  int handoff_kb, handoff_rmax;
+  unsigned long long *stats;  // [0] bytes streamed (4R^4 + 12R^2 per executed graph-iteration)  [1] graph-iterations
 };
 #define Q_HEAD(q) ((q).words + 0)
 #define Q_TAIL(q) ((q).words + 32)
 #define Q_REMAIN(q) ((q).words + 64)
+#define Q_ALIVE_KB(q) ((q).words + 65)
 #define Q_ERROR(q) ((q).words + 96)
+// KiB of a graph's similarity tensor as the kernel streams it (one pass = one iteration)
+__host__ __device__ __forceinline__ int mpm_slab_kb(int R, int RS) {
+  return (int)(((long long)R * R * R * RS * 4 + 1023) >> 10);
+}
 
 // Diagnostic build (-DGVAE_STREAM_STAMPS): lane 0 of a few work-groups prints the cycles its
 // items spent per phase.
@@ -549,7 +566,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
   float &s_nrm = lds_all[16];
   int *ctl = reinterpret_cast<int *>(lds_all + 17);
   int &s_item = ctl[0], &s_R = ctl[1], &s_last = ctl[2], &s_cont = ctl[3], &s_base = ctl[4],
-      &s_nb = ctl[5], &s_done = ctl[6], &s_alive = ctl[7];
+      &s_nb = ctl[5], &s_done = ctl[6], &s_alive = ctl[7], &s_alive_kb = ctl[8];
   float *lds = lds_all + kCtlFloats;
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef GVAE_STREAM_STAMPS
@@ -616,10 +633,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       // issued ahead of the X loads so that one round trip covers them all: the offset of the
       // graph's S block, and (one lane) what the last arriver of this iteration will need
       const int64_t s_off_g = S_off[g];
-      int done_r = 0, alive_r = 0;
+      int done_r = 0, alive_r = 0, alive_kb_r = 0;
       if (tid == 0) {
         done_r = __hip_atomic_load(&iters_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         alive_r = __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alive_kb_r = __hip_atomic_load(Q_ALIVE_KB(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       const int Aw_full = (R + n_blk - 1) / n_blk;
       const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
@@ -646,6 +664,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       if (tid == 0) {
         s_done = done_r;
         s_alive = alive_r;
+        s_alive_kb = alive_kb_r;
       }
       __syncthreads();
       TSTAMP(3);
@@ -725,7 +744,21 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           const int done = s_done + 1;
           __hip_atomic_store(&iters_done[g], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&q.arrive[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
+          int cont = (!(early_stop && d < tol) && done < iters) ? 1 : 0;
+          // one executed graph-iteration: S once, X read, X_new written, node block
+          __hip_atomic_fetch_add(&q.stats[0], 4ull * R2 * R2 + 12ull * R2, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&q.stats[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // latency-bound tail: the graph's remaining iterations go to the S-free kernel
+          // (the number of live KiB was read when the item started: a heuristic input)
+          if (cont && q.handoff && R <= q.handoff_rmax && s_alive_kb < q.handoff_kb &&
+              (q.sfree_ok[g] & 2)) {
+            cont = 0;
+            q.handoff[g] = 1;
+          }
+          if (!cont)
+            __hip_atomic_fetch_add(Q_ALIVE_KB(q), -mpm_slab_kb(R, RS), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
           if (cont) {
             const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high);
             s_nb = shape_next;
@@ -809,21 +842,27 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     const int R = Rarr[g];
     if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
     if (R <= 0 || R > r_max) { shape = 0; return 0; }
-    if (first_stop && (first_stop[g] != 0 || iters <= 1)) { shape = 0; return 0; }
+    if (first_stop && ((first_stop[g] & 1) != 0 || iters <= 1)) { shape = 0; return 0; }
     shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high);
     return mpm_shape_items(R, shape);
   };
-  int mine = 0, live = 0;
+  __shared__ int s_kb;
+  if (tid == 0) s_kb = 0;
+  __syncthreads();
+  int mine = 0, live = 0, kb = 0;
   for (int g = g_lo; g < g_hi; ++g) {
     int nb;
     const int n = items_of(g, nb);
     mine += n;
     live += n > 0;
+    if (n > 0) kb += mpm_slab_kb(Rarr[g], s_row_stride(Rarr[g], layout));
     q.arrive[g] = 0;
+    if (q.handoff) q.handoff[g] = 0;
     if (!first_stop) iters_done[g] = 0;
   }
   s_part[tid] = mine;
   s_live[tid] = live;
+  if (kb) atomicAdd(&s_kb, kb);
   __syncthreads();
   // inclusive scan (Hillis-Steele over 1024 entries)
   for (int off = 1; off < 1024; off <<= 1) {
@@ -845,6 +884,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
   if (tid == 1023) {
     *Q_TAIL(q) = s_part[1023];
     *Q_REMAIN(q) = s_live[1023];
+    *Q_ALIVE_KB(q) = s_kb;
   }
 }
 
@@ -859,7 +899,8 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
 // (pmin[a] in place of pmax[a] when A[i,j] < 0).  The rest is the iteration as the streaming
 // kernel does it: Xn[i,a] = fl(x0 * NS[i,a]) + canonical column sum of T over j (j == i: +0),
 // canonical norm, X = Xn / nrm, convergence test against x0.  One work-group per graph; every
-// later iteration streams S.  Writes X, iters_done[g] = 1 and stop[g] (1: converged).
+// later iteration streams S.  Writes X, iters_done[g] = 1 and stop[g] (bit 0: converged; bit 1: A is
+// 0/1 off the diagonal and P >= 0, i.e. the S-free form of the recurrence is valid for the graph).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
@@ -904,12 +945,17 @@ __global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
       pmin[a] = R > 1 ? mn : 0.0f;
     }
   }
-  if (a_in_lds)
-    for (int e = tid; e < R2; e += nt) {
-      const int i = e / R, j = e - i * R;
-      As[e] = Ag[(int64_t)i * ld + j];
-    }
-  __syncthreads();
+  // the S-free form of the recurrence (mpm_fused_kernel) holds for a 0/1 adjacency and
+  // non-negative P only: say whether this graph qualifies (the tail hand-off asks)
+  int weighted = 0;
+  for (int e = tid; e < R2; e += nt) {
+    const int i = e / R, j = e - i * R;
+    const float a = Ag[(int64_t)i * ld + j];
+    if (a_in_lds) As[e] = a;
+    weighted |= (i != j) && (a != 0.0f) && (a != 1.0f);
+    weighted |= (i != j) && !(Pg[(int64_t)i * ld + j] >= 0.0f);
+  }
+  const int binary_ok = !__syncthreads_or(weighted);
   for (int e = tid; e < R2; e += nt) {
     const int i = e / R, a = e - i * R;
     const float *arow = a_in_lds ? As + i * R : Ag + (int64_t)i * ld;
@@ -952,7 +998,7 @@ __global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
     float d = red[0];
     for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
     iters_done[g] = 1;
-    stop[g] = (early_stop && d < tol) ? 1 : 0;
+    stop[g] = ((early_stop && d < tol) ? 1 : 0) | (binary_ok ? 2 : 0);
   }
 }
 
@@ -1039,7 +1085,14 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
     int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done,
-    int64_t *__restrict__ perm, int n_perm, int32_t *__restrict__ status) {
+    int64_t *__restrict__ perm, int n_perm, int32_t *__restrict__ status,
+    const int32_t *__restrict__ resume, int r_lo, int r_hi) {
+  // resume != nullptr: only graphs with resume[g] != 0 and r_lo <= R <= r_hi run (one launch per
+  // size class of the kernel), continuing from the X in the caller's buffer after the
+  // iters_done[g] iterations another kernel has already executed
+  if (resume != nullptr &&
+      (resume[blockIdx.x] == 0 || Rarr[blockIdx.x] < r_lo || Rarr[blockIdx.x] > r_hi))
+    return;
   // control words at the front of the dynamic region (see mpm_stream_kernel): the 128-bit LDS
   // reads below need its base 16-byte aligned, which a static __shared__ object would undo
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -1110,12 +1163,12 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   const int n8 = R2 & ~7;
   const int JQ = (R + 3) >> 2;          // groups of 4 consecutive rows j
   const bool vec4 = (R & 3) == 0;
-  int done = 0;
+  int done = resume != nullptr ? iters_done[g] : 0;
 #ifdef GVAE_FUSED_STAMPS
   long long st_acc[5] = {0, 0, 0, 0, 0}, st_inner = 0;
   long long st_last = __builtin_readcyclecounter();
 #endif
-  for (int it = 0; it < iters; ++it) {
+  for (int it = done; it < iters; ++it) {
     STAMP(4);
     // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b]  (>= 0; Pp[a,a] = 0).  A lane takes one column a
     // and four consecutive rows j at a time: per 4 values of b it reads one 16-byte piece of
@@ -1270,7 +1323,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   // slowest graph's last MPM iteration.
   if (perm != nullptr) {
     __syncthreads();               // the last iteration's Xs (iters == 0: the initial X)
-    if (tid < 64) lsap_wave(Xs, R, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
+    if (tid < 64) lsap_wave(Xs, R, R, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
   }
 }
 
@@ -1350,18 +1403,67 @@ static inline int64_t mpm_queue_cap(int n_graphs, int r_max) {
   return (int64_t)n_graphs * r_max * MPM_MAX_COL_BLOCKS;
 }
 
-int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
-  // Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (granules) | arrive | stop flags
-  return pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 + pad256(8 * mpm_queue_cap(n_graphs, ldx)) +
-         2 * pad256(4LL * n_graphs);
+// statistics (256 B at the very front, wherever the batch size puts the rest; never cleared by a
+// launch) | Xnew (n_graphs*ldx*ldx floats) | queue words (512 B) | slots (granules) | arrive |
+// stop flags of the first-iteration kernel | hand-off flags
+struct MpmWs {
+  float *Xnew;
+  int32_t *words;
+  unsigned long long *slots;
+  int32_t *arrive, *stop, *handoff;
+  unsigned long long *stats;
+  int64_t bytes;
+};
+static MpmWs mpm_ws_carve(void *d_ws, int n_graphs, int ldx) {
+  MpmWs m;
+  char *w = (char *)d_ws;
+  m.stats = (unsigned long long *)w;
+  w += 256;
+  m.Xnew = (float *)w;
+  w += pad256((int64_t)n_graphs * ldx * ldx * 4);
+  m.words = (int32_t *)w;
+  w += 512;
+  m.slots = (unsigned long long *)w;
+  w += pad256(8 * mpm_queue_cap(n_graphs, ldx));
+  m.arrive = (int32_t *)w;
+  w += pad256(4LL * n_graphs);
+  m.stop = (int32_t *)w;
+  w += pad256(4LL * n_graphs);
+  m.handoff = (int32_t *)w;
+  w += pad256(4LL * n_graphs);
+  m.bytes = w - (char *)d_ws;
+  return m;
 }
+
+int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
+  return mpm_ws_carve(nullptr, n_graphs < 0 ? 0 : n_graphs, ldx < 0 ? 0 : ldx).bytes;
+}
+
+// slab bytes of live graphs below which gvae_match_stream hands the rest to the S-free kernel
+// (0: never).  128 MiB: one pass at the streaming rate of 6.7 TB/s takes 19 us, the latency of
+// one iteration's chain of dependent steps in the queue kernel.
+static int64_t g_handoff_bytes = 128LL << 20;
+#define GVAE_HANDOFF_MAX_NODES 32
+
+// control words | P (rows of R + 4 floats) | X | M | bit rows of A
+static inline size_t mpm_fused_lds_bytes(int r_max) {
+  return 4 * kCtlFloats + 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
+         4 * (size_t)r_max * ((r_max + 31) / 32);
+}
+constexpr size_t kMaxFusedLds = kMaxDynLds;
+static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                            int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                            int64_t strideX, int iters, float tol, int early_stop,
+                            int32_t *d_iters_done, int64_t *d_perm, int n_perm, int32_t *d_status,
+                            void *stream, const char *who, const int32_t *d_resume = nullptr);
 
 // first_iter_done: the first iteration was computed by mpm_first_iter_kernel (iters_done and the
 // stop flags in the workspace are set); the launch streams iterations 2..iters
 static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
                              int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
                              float tol, int early_stop, int32_t *d_iters_done, void *d_ws,
-                             bool first_iter_done, void *stream, bool profiled = true) {
+                             bool first_iter_done, void *stream, bool profiled = true,
+                             int handoff_rmax = 0) {
   GVAE_REQUIRE(d_S && d_S_off && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "mpm_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ldx && iters >= 0, GVAE_EINVAL,
@@ -1383,17 +1485,20 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
                        n_graphs);
     return check_launch("mpm_stream");
   }
-  char *w = (char *)d_ws;
-  float *Xnew = (float *)w;
-  w += pad256((int64_t)n_graphs * ldx * ldx * 4);
+  const MpmWs m = mpm_ws_carve(d_ws, n_graphs, ldx);
+  float *Xnew = m.Xnew;
   MpmQueue q;
-  q.words = (int32_t *)w;
-  w += 512;
-  q.slots = (unsigned long long *)w;
-  w += pad256(8 * mpm_queue_cap(n_graphs, ldx));
-  q.arrive = (int32_t *)w;
-  w += pad256(4LL * n_graphs);
-  const int32_t *first_stop = first_iter_done ? (const int32_t *)w : nullptr;
+  q.words = m.words;
+  q.slots = m.slots;
+  q.arrive = m.arrive;
+  q.stats = m.stats;
+  // the S-free kernel takes over the latency-bound tail (callers that hold A and P only)
+  const bool handoff = handoff_rmax > 0 && first_iter_done && early_stop && g_handoff_bytes > 0;
+  q.handoff = handoff ? m.handoff : nullptr;
+  q.sfree_ok = m.stop;
+  q.handoff_rmax = handoff_rmax;
+  q.handoff_kb = (int)(g_handoff_bytes >> 10 > INT32_MAX ? INT32_MAX : g_handoff_bytes >> 10);
+  const int32_t *first_stop = first_iter_done ? m.stop : nullptr;
   const int64_t n_items = mpm_queue_cap(n_graphs, r_max);
   q.cap = (unsigned)n_items;
   const int64_t strideXnew = (int64_t)ldx * ldx;
@@ -1508,6 +1613,29 @@ int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layou
                            early_stop, d_iters_done, ws, false, stream, /*profiled=*/false);
 }
 
+int gvae_set_stream_handoff_bytes(int64_t bytes) {
+  GVAE_REQUIRE(bytes >= 0, GVAE_EINVAL, "set_stream_handoff_bytes: negative threshold");
+  g_handoff_bytes = bytes;
+  return GVAE_OK;
+}
+
+int gvae_mpm_stream_stats(void *d_ws, int64_t *h_bytes, int64_t *h_graph_iterations, int reset,
+                          void *stream) {
+  GVAE_REQUIRE(d_ws, GVAE_EINVAL, "mpm_stream_stats: null workspace");
+  const MpmWs m = mpm_ws_carve(d_ws, 0, 0);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long h[2] = {0, 0};
+  GVAE_REQUIRE(hipMemcpyAsync(h, m.stats, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                   hipStreamSynchronize(s) == hipSuccess,
+               GVAE_ELAUNCH, "mpm_stream_stats: copy failed");
+  if (reset)
+    GVAE_REQUIRE(hipMemsetAsync(m.stats, 0, sizeof(h), s) == hipSuccess, GVAE_ELAUNCH,
+                 "mpm_stream_stats: reset failed");
+  if (h_bytes) *h_bytes = (int64_t)h[0];
+  if (h_graph_iterations) *h_graph_iterations = (int64_t)h[1];
+  return GVAE_OK;
+}
+
 int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                       int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                       const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
@@ -1537,29 +1665,40 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
                  lds, hipGetErrorString(e));
   }
   // the stop flags sit behind the arrival counters in the workspace (see mpm_stream_launch)
-  int32_t *stop = (int32_t *)((char *)d_ws + pad256((int64_t)n_graphs * ldx * ldx * 4) + 512 +
-                              pad256(8 * mpm_queue_cap(n_graphs, ldx)) + pad256(4LL * n_graphs));
+  const MpmWs m = mpm_ws_carve(d_ws, n_graphs, ldx);
   hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(r_max >= 48 ? 1024 : 256), lds, s, d_A,
                      d_P, d_NS, d_R, r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, a_in_lds,
-                     d_iters_done, stop);
+                     d_iters_done, m.stop);
   rc = check_launch("match_stream");
   if (rc) return rc;
   if (iters == 1) return GVAE_OK;
-  return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
-                           early_stop, d_iters_done, d_ws, true, stream);
+  // Graphs small enough for the S-free kernel may be handed to it once the batch is bound by
+  // the latency of an iteration rather than by HBM (see MpmQueue): same X, same iteration
+  // counts, bit for bit, whichever kernel runs an iteration.
+  // Only graphs of at most 32 nodes: there an S-free iteration takes 5 us against the 19 us of
+  // the queue kernel's chain; from 33 nodes on the S-free kernel needs 18 us and more per
+  // iteration (one work-group per graph), which is no faster than streaming.
+  const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
+  const bool handoff = early_stop && g_handoff_bytes > 0 && r_cap > 0;
+  rc = mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
+                         early_stop, d_iters_done, d_ws, true, stream, true, handoff ? r_cap : 0);
+  if (rc || !handoff) return rc;
+  return mpm_fused_launch(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_cap, d_X, ldx, strideX, iters, tol,
+                          early_stop, d_iters_done, nullptr, 0, nullptr, stream, "match_stream (tail)",
+                          m.handoff);
 }
 
 static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                             int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
                             int64_t strideX, int iters, float tol, int early_stop,
                             int32_t *d_iters_done, int64_t *d_perm, int n_perm, int32_t *d_status,
-                            void *stream, const char *who) {
+                            void *stream, const char *who, const int32_t *d_resume) {
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done, GVAE_EINVAL, "%s: null pointer", who);
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "%s: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", who, n_graphs, r_max, ld, ldx);
-  const size_t lds = 4 * kCtlFloats + 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
-                     4 * (size_t)r_max * ((r_max + 31) / 32);
-  GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxDynLds, GVAE_ELIMIT,
+  size_t lds = mpm_fused_lds_bytes(r_max);
+  int r_lo = 0, r_hi = r_max;
+  GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxFusedLds, GVAE_ELIMIT,
                "%s: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", who, r_max, lds);
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1572,13 +1711,29 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
                    hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld, stride, d_X,
-                       ldx, strideX, iters, tol, early_stop, d_iters_done, d_perm, n_perm, d_status);
+                       ldx, strideX, iters, tol, early_stop, d_iters_done, d_perm, n_perm, d_status,
+                       d_resume, r_lo, r_hi);
     return GVAE_OK;
   };
-  int rc;
-  if (r_max <= 32) rc = launch(mpm_fused_kernel<256, 4>, 256);
-  else if (r_max <= 64) rc = launch(mpm_fused_kernel<512, 8>, 512);
-  else rc = launch(mpm_fused_kernel<1024, 16>, 1024);
+  auto pick = [&](int rm) -> int {
+    if (rm <= 32) return launch(mpm_fused_kernel<256, 4>, 256);
+    if (rm <= 64) return launch(mpm_fused_kernel<512, 8>, 512);
+    return launch(mpm_fused_kernel<1024, 16>, 1024);
+  };
+  int rc = GVAE_OK;
+  if (d_resume == nullptr) {
+    rc = pick(r_max);
+  } else {
+    // resumed graphs: each by the kernel shape of its own size class (work-groups of graphs
+    // outside the class, or not handed over, leave at once)
+    const int hi[3] = {32, 64, GVAE_MAX_NODES_LDS};
+    for (int c = 0, lo = 1; c < 3 && !rc && lo <= r_max; lo = hi[c] + 1, ++c) {
+      r_lo = lo;
+      r_hi = r_max < hi[c] ? r_max : hi[c];
+      lds = mpm_fused_lds_bytes(r_hi);
+      rc = pick(r_hi);
+    }
+  }
   if (rc) return rc;
   return check_launch(who);
 }

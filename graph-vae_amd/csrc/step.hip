@@ -591,6 +591,8 @@ int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which
     case 14: *out_ptr = w.Ahat; *out_count = B * N * N; break;
     case 15: *out_ptr = w.dY; *out_count = B * N * d->H; break;
     case 16: *out_ptr = w.dgvec; *out_count = B * d->H; break;
+    case 17: *out_ptr = reinterpret_cast<float *>(w.mpm_ws);
+             *out_count = gvae_mpm_stream_ws_bytes(n_graphs, d->N) / 4; break;
     default: return set_error(GVAE_EINVAL, "read_debug: unknown buffer %d", which);
   }
   return GVAE_OK;

@@ -53,6 +53,8 @@ def lib() -> ctypes.CDLL:
                                       c_void_p]
         L.gvae_mpm_stream_static.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                              c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p]
+        L.gvae_set_stream_handoff_bytes.argtypes = [c_int64]
+        L.gvae_mpm_stream_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int, c_void_p]
         L.gvae_match_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                         c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]
@@ -186,6 +188,20 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
     return done
 
 
+def set_stream_handoff_bytes(n: int) -> None:
+    """Live similarity-tensor bytes below which the streamed matching of the step hands its
+    last unconverged graphs to the S-free kernel (0: never; default 128 MiB)."""
+    _check(lib().gvae_set_stream_handoff_bytes(int(n)))
+
+
+def mpm_stream_stats(ws_ptr: int, reset: bool = False):
+    """(algorithmic bytes, graph-iterations) the streaming kernel executed through the workspace
+    at `ws_ptr` since the last reset; synchronises the current stream."""
+    b, n = c_int64(0), c_int64(0)
+    _check(lib().gvae_mpm_stream_stats(ws_ptr, ctypes.byref(b), ctypes.byref(n), int(reset), _stream()))
+    return b.value, n.value
+
+
 STATIC_SCRATCH_BYTES = 2 << 20
 
 
@@ -205,7 +221,7 @@ def mpm_stream_static(S, S_off, R, r_max: int, X, done, iters: int = 50, tol: fl
 
 
 def match_stream(A, P, NS, R, R_host, X, iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
-                 layout: int = S_PADDED):
+                 layout: int = S_PADDED, ws: torch.Tensor | None = None):
     """Similarity tensor + streamed MPM from the uniform start in one library call
     (gvae_match_stream): returns (S, S_off, iterations); X (G, N, N) is output only."""
     _dev(A, torch.float32), _dev(P, torch.float32), _dev(NS, torch.float32), _dev(R, torch.int32)
@@ -215,7 +231,9 @@ def match_stream(A, P, NS, R, R_host, X, iters: int = 50, tol: float = 1e-4, ear
     S = torch.empty(max(total, 4), dtype=torch.float32, device=A.device)
     S_off = torch.tensor(offs, dtype=torch.int64, device=A.device)
     done = torch.empty(G, dtype=torch.int32, device=A.device)
-    ws = torch.empty(lib().gvae_mpm_stream_ws_bytes(G, X.shape[1]), dtype=torch.uint8, device=A.device)
+    need = lib().gvae_mpm_stream_ws_bytes(G, X.shape[1])
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=A.device)
     _check(lib().gvae_match_stream(A.data_ptr(), P.data_ptr(), NS.data_ptr(), R.data_ptr(), G, N, N * N,
                                    max(R_host), layout, S.data_ptr(), S_off.data_ptr(), X.data_ptr(),
                                    X.shape[1], X.shape[1] * X.shape[2], iters, tol, int(early_stop),

@@ -364,6 +364,18 @@ class StepEngine:
         finally:
             self._cur = cur
 
+    def stream_stats(self, reset: bool = False):
+        """(algorithmic bytes, graph-iterations) the streaming MPM kernel has executed for the
+        current slot's batch size since the last reset (gvae_mpm_stream_stats); synchronises the
+        current stream.  The counters live in the slot's workspace at a place that depends on the
+        batch size: read them between forwards of equally sized batches."""
+        if self._fwd_batch is None:
+            raise _hip.GvaeHipError("stream_stats called before a forward")
+        ptr, cnt = c_void_p(), c_int64()
+        _hip._check(self.L.gvae_step_read_debug(ctypes.byref(self.dims), self._fwd_batch[0].num_graphs,
+                                                self._ws.data_ptr(), 17, ctypes.byref(ptr), ctypes.byref(cnt)))
+        return _hip.mpm_stream_stats(ptr.value, reset)
+
     # ------------------------------------------------------------------ inspection (tests)
     _DEBUG = {"vec_logits": 0, "node_logits": 1, "P": 2, "X": 3, "mu": 4, "logvar_raw": 5, "rec_i": 6,
               "kl_i": 7, "status": 8, "Y1": 9, "H1": 10, "Y2": 11, "H2": 12, "gvec": 13, "Ahat": 14,

@@ -111,12 +111,34 @@ int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layou
  * back: with a uniform X0, max_b S[i,j,a,b]*x0 = (max_b S[i,j,a,b])*x0 exactly (rounding is
  * monotone), and the row maximum of S is max(0, A[i,j]*max_{b!=a} P[a,b]) (the minimum over b
  * when A[i,j] < 0), so that iteration costs O(R^3) per graph instead of one pass over S; every
- * later iteration streams S.  d_X is output only.  Same X, same iteration counts as the two
- * calls, bit for bit.  d_ws: gvae_mpm_stream_ws_bytes. */
+ * later iteration streams S, except those of the latency-bound tail, which the S-free kernel
+ * takes over (gvae_set_stream_handoff_bytes).  d_X is output only.  Same X, same iteration
+ * counts as the two calls, bit for bit.  d_ws: gvae_mpm_stream_ws_bytes. */
 int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                       int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                       const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
                       float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
+
+/* Tail hand-off of gvae_match_stream.  With early stop, the last unconverged graphs of a batch
+ * iterate on a nearly empty device, where an iteration costs the latency of the queue kernel's
+ * chain of dependent steps (about 19 us), not HBM time.  Once the similarity tensors of the
+ * graphs still iterating add up to less than `bytes` (default 128 MiB = 19 us at the streaming
+ * rate), a graph of at most 32 nodes (where an S-free iteration takes 5 us; larger graphs gain
+ * nothing) with a 0/1 adjacency leaves the queue at
+ * the end of its current iteration and the S-free kernel runs its remaining iterations after
+ * the streaming launch: same X and iteration counts, bit for bit.  0 = never hand off.  Applies
+ * to gvae_match_stream and the streamed step only (gvae_mpm_stream takes an arbitrary S, for
+ * which no S-free form exists).  Process-wide setting; no counterpart in the reference. */
+int gvae_set_stream_handoff_bytes(int64_t bytes);
+
+/* What the streaming kernel has executed through this workspace (a gvae_mpm_stream_ws_bytes
+ * buffer; the counters sit in its first 16 bytes) since the last reset: the algorithmic bytes
+ * sum(4 R^4 + 12 R^2) and the number of graph-iterations it streamed (iterations done by the
+ * first-iteration shortcut or by the S-free tail are not among them).  Copies the two counters
+ * to the host, synchronising `stream`; reset != 0 then clears them (a fresh workspace holds
+ * garbage: reset it once before measuring).  Measurement aid. */
+int gvae_mpm_stream_stats(void *d_ws, int64_t *h_bytes, int64_t *h_graph_iterations, int reset,
+                          void *stream);
 
 /* ---------------------------------------------------------------------------
  * Max-pool matching without S: same recurrence and same bits as
@@ -267,6 +289,7 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
 
 /* Pointer into the workspace for inspection by tests: which = 0 edge logits (B,U),
  * 1 node logits (B,N), 2 P (B,N,N), 3 X (B,N,N), 4 mu, 5 logvar (pre-clamp) (B,Z),
+ * 17 the streamed matching's workspace (for gvae_mpm_stream_stats; count = its bytes / 4),
  * 6 rec_i, 7 kl_i (B), 8 assignment status (B, int32), 9 Y1, 10 H1, 11 Y2, 12 H2 (B,N,H:
  * aggregated pre-BatchNorm values without bias / post-ReLU activations of the two GCN
  * layers), 13 pooled vector (B,H), 14 normalised adjacency (B,N,N), 15 dY of layer 1 after

@@ -433,3 +433,57 @@ def test_dense_layout_wide_workgroups(hip):
     assert torch.equal(dd, dp) and torch.equal(Xd, Xp)
     Xo, done = ora.mpm_sfree(As[0], Ps[0], None, 6, 1e-4, True)
     assert int(dp[0]) == done and np.array_equal(Xp[0, :49, :49].cpu().numpy(), Xo)
+
+
+def test_match_stream_tail_handoff(hip):
+    """gvae_match_stream hands the latency-bound tail of a batch to the S-free kernel: with the
+    hand-off off, at its default and forced from the first streamed iteration on, X and iteration
+    counts equal the purely streamed matching bit for bit; a weighted graph (for which no S-free
+    form exists) is never handed off; the workspace counters say what the streaming kernel ran."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(23)
+    sizes = (32, 31, 17, 40, 9, 64, 33, 2, 25, 48, 12, 70)
+    As, Ps = [], []
+    for k, R in enumerate(sizes):
+        w = (rng.random((R, R)) < 0.35).astype(np.float32)
+        if k == 4:
+            w = w * rng.normal(0.8, 0.5, (R, R)).astype(np.float32)       # weighted: not eligible
+        up = np.triu(w, 1)
+        As.append((up + up.T + np.eye(R, dtype=np.float32)).astype(np.float32))
+        lg = np.triu(rng.normal(0, 0.6, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    N = max(sizes)
+    Rh = list(sizes)
+    A = torch.from_numpy(_pack(As, N)).to(dev)
+    P = torch.from_numpy(_pack(Ps, N)).to(dev)
+    R = torch.tensor(Rh, dtype=torch.int32, device=dev)
+    NS = hip.node_sim(A, P, R)
+    S, S_off = hip.edge_sim(A, P, NS, R, Rh, hip.S_PADDED)
+    X_ref = hip.x0_uniform(Rh, N, dev)
+    done_ref = hip.mpm_stream(S, S_off, R, N, X_ref, 50, 1e-4, True, layout=hip.S_PADDED)
+    it = done_ref.cpu().numpy().astype(np.int64)
+    r = np.array(Rh, dtype=np.int64)
+    per_gi = 4 * r ** 4 + 12 * r ** 2
+    ws = torch.zeros(hip.lib().gvae_mpm_stream_ws_bytes(len(Rh), N), dtype=torch.uint8, device=dev)
+    try:
+        streamed = {}
+        for name, thr in (("off", 0), ("default", 128 << 20), ("always", 1 << 50)):
+            hip.set_stream_handoff_bytes(thr)
+            hip.mpm_stream_stats(ws.data_ptr(), reset=True)
+            X = torch.zeros_like(X_ref)
+            _S, _o, done = hip.match_stream(A, P, NS, R, Rh, X, 50, 1e-4, True, ws=ws)
+            assert torch.equal(done, done_ref), name
+            for g, rr in enumerate(Rh):
+                assert torch.equal(X[g, :rr, :rr], X_ref[g, :rr, :rr]), (name, g)
+            streamed[name] = hip.mpm_stream_stats(ws.data_ptr())
+        # iteration 1 comes from the first-iteration kernel; the rest was streamed ...
+        assert streamed["off"] == (int((per_gi * (it - 1)).sum()), int((it - 1).sum()))
+        # ... or, handed off at once, one streamed iteration per graph of at most 32 nodes that
+        # needed a second one (larger graphs and the weighted graph are never handed off)
+        keep = (np.arange(len(Rh)) == 4) | (r > 32)
+        one = np.where(keep, it - 1, np.minimum(it - 1, 1))
+        assert streamed["always"] == (int((per_gi * one).sum()), int(one.sum()))
+        assert streamed["always"][1] <= streamed["default"][1] <= streamed["off"][1]
+        assert it[4] > 2 and it.max() > 10
+    finally:
+        hip.set_stream_handoff_bytes(128 << 20)
