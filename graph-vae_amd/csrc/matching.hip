@@ -590,6 +590,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       const unsigned slot = ticket % q.cap, want = MPM_LAP_TAG(ticket, q.cap);
       int got = 0;
       unsigned item = MPM_NULL_ITEM;
+      int tail_seen = -1;
       for (unsigned spins = 0;; ++spins) {
         const unsigned long long v =
             __hip_atomic_load(&q.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -601,9 +602,18 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_store(&q.slots[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        if ((spins & 3u) == 3u &&
-            __hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0)
-          break;                                   // every graph is finished: nothing will come
+        if ((spins & 3u) == 3u) {
+          if (__hip_atomic_load(Q_REMAIN(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0)
+            break;                                 // every graph is finished: nothing will come
+          // the bound is on waiting WITHOUT progress of the queue: a consumer whose ticket lies
+          // beyond the tail idles for as long as the launch runs (seconds at hundreds of
+          // iterations), which is not a fault while items are still being pushed
+          const int tail_now = __hip_atomic_load(Q_TAIL(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tail_now != tail_seen) {
+            tail_seen = tail_now;
+            spins = 0;
+          }
+        }
         if (spins > MPM_SPIN_LIMIT) {              // never expected; do not hang the device
           __hip_atomic_store(Q_ERROR(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;

@@ -247,3 +247,37 @@ def test_chunked_matching_at_128_nodes_vs_oracle():
     assert n1 == 3 and n2 == 1
     assert rec1 == rec2 and kl1 == kl2
     assert torch.equal(perm1, perm2) and torch.equal(it1, it2) and torch.equal(g1, g2)
+
+
+@pytest.mark.timeout(300)
+def test_long_launch_at_300_iterations():
+    """max_nodes 64, batch 1024, 300 MPM iterations without early stop in ONE persistent launch
+    (64 GiB of similarity tensors streamed 299 times, about three seconds): the queue's idle
+    consumers wait that long without tripping the no-progress bound; iteration counts, and X /
+    permutation of spot graphs against the C oracle."""
+    from graphvae import _hip
+    from graphvae.data import synthetic_batch
+    N, B, iters = 64, 1024, 300
+    free, _total = torch.cuda.mem_get_info()
+    if free < 80 << 30:
+        pytest.skip("needs 80 GiB of free device memory")
+    hb = synthetic_batch("dense", B, N, "deg", seed=77)
+    gen = torch.Generator().manual_seed(6)
+    lg = torch.triu(torch.randn(B, N, N, generator=gen) * 1.5, 1)
+    P = torch.sigmoid(lg + lg.transpose(1, 2)).contiguous()
+    Ad, Pd = hb.adj_dense.to(DEV), P.to(DEV)
+    Rh = list(hb.r_host)
+    Rt = hb.num_real_nodes.to(DEV)
+    NS = _hip.node_sim(Ad, Pd, Rt)
+    X = torch.zeros(B, N, N, device=DEV)
+    S, S_off, done = _hip.match_stream(Ad, Pd, NS, Rt, Rh, X, iters, 1e-4, False)
+    torch.cuda.synchronize()
+    assert done.cpu().tolist() == [iters] * B            # a queue fault would read -code everywhere
+    perm, status = _hip.lsap(X, Rt, N)
+    assert int(status.sum()) == 0
+    for g in (0, 511, 1023):
+        Xo, it = ora.mpm_sfree(hb.adj_dense[g].numpy(), P[g].numpy(), iters=iters, early_stop=False)
+        assert it == iters and np.array_equal(X[g].cpu().numpy(), Xo)
+        assert np.array_equal(perm[g].cpu().numpy(), ora.assign_perm(Xo))
+    del S
+    torch.cuda.empty_cache()
