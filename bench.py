@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the GraphVAE training step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5] [--matching stream|fused]
+  python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c5] [--matching stream|fused]
 
 One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE for N > 1).  A step is one
 full optimisation step on one batch of synthetic graphs already resident in HBM: encoder,
@@ -10,6 +10,8 @@ all-reduce (RCCL), clipping and Adam.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs).  c2 keeps the per-GPU batch fixed ("scaling": "weak"); the
 others divide their global batch over the ranks ("strong"):
+  c1  ENZYMES-shaped graphs of at most 40 nodes (reference configs/enzymes_deg.yaml:5), batch 32:
+      the reference's own CPU-runnable configuration
   c2  dense graphs, max_nodes 32, batch 256 per GPU         (default; matching-dominated)
   c3  ENZYMES-shaped graphs padded to 126, batch 64 over all ranks
   c4  dense graphs, max_nodes 64, batch 1024 over all ranks, fixed MPM iterations (--mpm-iters)
@@ -41,9 +43,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+VALU_F32_PEAK_TFLOPS = 157.3  # 256 CUs x 4 SIMDs x 32 fp32 FMA lanes x 2 flop x 2.4 GHz
 
 WORKLOADS = {
     #        kind       N    global batch (None = per-GPU 256)   early_stop
+    "c1": ("enzymes_filtered", 40, 32, True),
     "c2": ("dense", 32, None, True),
     "c3": ("enzymes", 126, 64, True),
     "c4": ("dense", 64, 1024, False),
@@ -62,7 +66,7 @@ def parse():
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-leg", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -80,7 +84,7 @@ def make_model_and_batches(args, rank, world, device, matching, n_batches=2):
     return model, [b.to(device) for b in host], host, per_gpu, N, early_stop
 
 
-def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, engine=None):
+def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, engine=None, flops_acc=None):
     for s in range(warmup):
         step_fn(batches[s % len(batches)], 0.25, 1.0)
     if dist.is_initialized():
@@ -92,6 +96,9 @@ def timed_steps(step_fn, batches, steps, warmup, world, device, iters_acc=None, 
         if iters_acc is not None:
             step_fn.wait()                      # the iteration counts come from the side stream
             iters_acc += engine.iters_done.sum()
+            if flops_acc is not None:           # 4 R^3 per executed MPM iteration of a graph
+                r3 = batches[s % len(batches)].num_real_nodes.to(torch.float64) ** 3
+                flops_acc += (engine.iters_done.to(torch.float64) * 4.0 * r3).sum()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -278,8 +285,27 @@ def main():
                     "streamed_iters_per_graph": streamed_gi / (args.steps * per_gpu),
                     "tail_sfree_ms_per_step": ms_tail / max(1, args.steps),
                     "edge_sim_GBps": (float(np.sum(4.0 * r ** 4)) / (ms_es * 1e-3) / 1e9) if ms_es > 0 else None}
+        fused_roof = None
+        if leg == "fused":
+            # the S-free kernel is bound by vector fp32 work (4 R^3 flop per graph-iteration, operands
+            # resident in LDS), not by HBM: the same K steps again with events around its launches
+            _hip.profile_reset()
+            _hip.profile_enable(True)
+            step_fn.wait()
+            torch.cuda.synchronize()
+            flops_acc = torch.zeros((), dtype=torch.float64, device=device)
+            timed_steps(step_fn, batches, args.steps, 0, world, device, iters_acc, eng, flops_acc)
+            _hip.profile_enable(False)
+            ms_f, n_f = _hip.profile_read("mpm_fused")
+            _hip.profile_reset()
+            tf = float(flops_acc.item()) / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+            fused_roof = {"kernel": "mpm_fused_kernel", "bound": "valu", "achieved": tf,
+                          "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_F32_PEAK_TFLOPS,
+                          "traffic": None, "launches": int(n_f), "avg_launch_ms": ms_f / max(1, n_f),
+                          "flop_per_launch": float(flops_acc.item()) / max(1, n_f),
+                          "mean_mpm_iters_per_graph": float(iters_acc.item()) / (args.steps * per_gpu)}
         results[leg] = {"value": world * per_gpu * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
-                        "per_gpu_batch": per_gpu}
+                        "per_gpu_batch": per_gpu, "roofline": fused_roof}
         del model, batches, step_fn, eng
         torch.cuda.empty_cache()
 
@@ -300,9 +326,19 @@ def main():
         line["roofline"] = roof
     if "fused" in results and args.matching != "fused":
         line["fused"] = {"value": results["fused"]["value"], "ms_per_step": results["fused"]["ms_per_step"],
+                         "roofline": results["fused"]["roofline"],
                          "note": "same step with the S-free LDS-resident MPM (bit-identical results)"}
+    elif args.matching == "fused":
+        line["roofline"] = main_leg["roofline"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # all host threads torch was given, then one thread; each about --cpu-seconds of CPU work
         line["cpu_baseline"] = cpu_baseline(args, host_batches, early_stop)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            line["cpu_baseline_1thread"] = cpu_baseline(args, host_batches, early_stop)
+        finally:
+            torch.set_num_threads(threads)
     if dist.is_initialized():
         dist.destroy_process_group()
     sys.stdout.flush()

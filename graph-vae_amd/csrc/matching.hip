@@ -7,6 +7,7 @@
 #include "gvae_common.h"
 
 #include <mutex>
+#include <type_traits>
 
 namespace gvae {
 
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void edge_sim_kernel(const float *__restrict__
 // ---------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <int V>
 struct VecT;
 template <>
@@ -371,6 +373,16 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
   mpm_iter_body<V>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
 }
 
+// value of `v` in lane `lane` (a compile-time constant after unrolling) for the whole wavefront
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// maximum over the wavefront, in every lane: DPP within rows of 16 lanes, then the four rows
+__device__ __forceinline__ float wave_max(float m) {
+  m = group_max(m, 4);
+  return fmaxf(fmaxf(lane_value(m, 0), lane_value(m, 16)), fmaxf(lane_value(m, 32), lane_value(m, 48)));
+}
+
 // chain over x[0..n) (n % 8 == 0) continuing the 8 lane accumulators; lanes 0..7 of wave 0
 __device__ __forceinline__ float norm_chain(const float *x, int n, int lane, float acc) {
   // the fused chain itself is serial (one dependent fma per element of the lane); the next
@@ -402,9 +414,9 @@ __device__ __forceinline__ float norm_chain(const float *x, int n, int lane, flo
 
 // fold lanes 0..7 in order and fuse the tail (executed by the whole first wave)
 __device__ __forceinline__ float norm_finish(float acc, const float *tail, int ntail) {
-  float s = __shfl(acc, 0, 64);
+  float s = lane_value(acc, 0);
 #pragma unroll
-  for (int l = 1; l < 8; ++l) s = s + __shfl(acc, l, 64);
+  for (int l = 1; l < 8; ++l) s = s + lane_value(acc, l);
   int k = 0;
   if (ntail >= 4)
     for (; k < 4; ++k) s = s + __fmul_rn(tail[k], tail[k]);  // rounded squares, not fused
@@ -1087,9 +1099,283 @@ __device__ __forceinline__ void cascade_chains(const float *__restrict__ Mcol, i
   }
 }
 
-// LDS: Pp (R rows of P with the diagonal zeroed, row stride R+4 so that lanes holding
-// consecutive rows read 16-byte pieces conflict-free), X (R*R), M (R*R), A as bit rows.
+// The same for columns that the canonical order sums as four interleaved strands (ilp4_sum):
+// strand s takes the terms j = 4t + s of the first 4*floor(R/4) rows, cascading after every 16
+// of ITS terms, i.e. after every 64 consecutive j; the remaining rows go to strand 0 after the
+// strands' levels are folded; then strand 0 receives strands 1, 2, 3.  Walking j upwards visits
+// the strands round-robin, so one pass over the column feeds all 4*NCH accumulators.  Valid for
+// R < 1024 (a strand never reaches its second cascade level).
+template <int NCH>
+__device__ __forceinline__ void ilp4_chains(const float *__restrict__ Mcol, int R,
+                                            const uint32_t *const (&bits)[NCH],
+                                            float (&out)[NCH]) {
+  float l0[NCH][4], l1[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l0[c][q] = l1[c][q] = 0.f;
+  const int n44 = (R >> 2) << 2;
+  int i = 0;
+  for (; i + 16 <= n44; i += 16) {
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = Mcol[(i + t) * R];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t w = bits[c][i >> 5] >> (i & 31);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) l0[c][t & 3] += ((w >> t) & 1u) ? v[t] : 0.0f;
+    }
+    if (((i + 16) & 63) == 0) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          l1[c][q] += l0[c][q];
+          l0[c][q] = 0.f;
+        }
+    }
+  }
+  for (; i < n44; i += 4) {
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = Mcol[(i + t) * R];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t w = bits[c][i >> 5] >> (i & 31);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) l0[c][t] += ((w >> t) & 1u) ? v[t] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l0[c][q] += l1[c][q];   // the higher levels are +0: adding them changes nothing
+  for (; i < R; ++i) {
+    const float v = Mcol[i * R];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) l0[c][0] += ((bits[c][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    l0[c][0] += l0[c][1];
+    l0[c][0] += l0[c][2];
+    l0[c][0] += l0[c][3];
+    out[c] = l0[c][0];
+  }
+}
+
+// The column sums with byte masks (one byte per (i, j): 1 when j is a neighbour of i): a term is
+// fma(M[j,a], mask, acc) -- M * 1 + acc rounds once, exactly as the sum does, and M * 0 + acc
+// leaves acc as it is -- so a pair of chains advances with one packed fma; the sixteen masks of
+// a chain and a block come with one 16-byte read.  mrow[c]: byte row of chain c, 16-byte aligned.
+__device__ __forceinline__ float mask_byte(const uint32_t (&w)[2], int t) {
+  return (float)((w[t >> 2] >> (8 * (t & 3))) & 0xFFu);      // v_cvt_f32_ubyteN
+}
+
+template <int NCH>
+__device__ __forceinline__ void cascade_chains_b(const float *__restrict__ Mcol, int R,
+                                                 const uint8_t *const (&mrow)[NCH],
+                                                 float (&out)[NCH]) {
+  static_assert(NCH % 2 == 0, "chains advance in pairs");
+  constexpr int NP = NCH / 2;
+  f32x2_t l0[NP], l1[NP], l2[NP], l3[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) l0[c] = l1[c] = l2[c] = l3[c] = f32x2_t{0.f, 0.f};
+  int i = 0;
+  while (i + 16 <= R) {
+#pragma unroll
+    for (int h = 0; h < 16; h += 8) {      // eight terms at a time keeps the live registers down
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = Mcol[(i + h + t) * R];
+      uint32_t mk[NCH][2];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x2_t q = *reinterpret_cast<const u32x2_t *>(mrow[c] + i + h);
+        mk[c][0] = q.x, mk[c][1] = q.y;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+          l0[c] = __builtin_elementwise_fma(f32x2_t{v[t], v[t]},
+                                            f32x2_t{mask_byte(mk[2 * c], t), mask_byte(mk[2 * c + 1], t)},
+                                            l0[c]);
+    }
+    i += 16;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      l1[c] += l0[c];
+      l0[c] = f32x2_t{0.f, 0.f};
+    }
+    if ((i & 0xF0) == 0) {
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        l2[c] += l1[c];
+        l1[c] = f32x2_t{0.f, 0.f};
+      }
+      if ((i & 0xF00) == 0) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+          l3[c] += l2[c];
+          l2[c] = f32x2_t{0.f, 0.f};
+        }
+      }
+    }
+  }
+  for (; i < R; ++i) {
+    const float v = Mcol[i * R];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+      l0[c] = __builtin_elementwise_fma(f32x2_t{v, v},
+                                        f32x2_t{(float)mrow[2 * c][i], (float)mrow[2 * c + 1][i]}, l0[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    l0[c] += l1[c];
+    l0[c] += l2[c];
+    l0[c] += l3[c];
+    out[2 * c] = l0[c].x;
+    out[2 * c + 1] = l0[c].y;
+  }
+}
+
+template <int NCH>
+__device__ __forceinline__ void ilp4_chains_b(const float *__restrict__ Mcol, int R,
+                                              const uint8_t *const (&mrow)[NCH],
+                                              float (&out)[NCH]) {
+  static_assert(NCH % 2 == 0, "chains advance in pairs");
+  constexpr int NP = NCH / 2;
+  f32x2_t l0[NP][4], l1[NP][4];
+#pragma unroll
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l0[c][q] = l1[c][q] = f32x2_t{0.f, 0.f};
+  const int n44 = (R >> 2) << 2;
+  int i = 0;
+  for (; i + 16 <= n44; i += 16) {
+#pragma unroll
+    for (int h = 0; h < 16; h += 8) {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = Mcol[(i + h + t) * R];
+      uint32_t mk[NCH][2];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x2_t q = *reinterpret_cast<const u32x2_t *>(mrow[c] + i + h);
+        mk[c][0] = q.x, mk[c][1] = q.y;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+          l0[c][t & 3] = __builtin_elementwise_fma(
+              f32x2_t{v[t], v[t]}, f32x2_t{mask_byte(mk[2 * c], t), mask_byte(mk[2 * c + 1], t)},
+              l0[c][t & 3]);
+    }
+    if (((i + 16) & 63) == 0) {
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          l1[c][q] += l0[c][q];
+          l0[c][q] = f32x2_t{0.f, 0.f};
+        }
+    }
+  }
+  for (; i < n44; i += 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float v = Mcol[(i + t) * R];
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+        l0[c][t] = __builtin_elementwise_fma(
+            f32x2_t{v, v}, f32x2_t{(float)mrow[2 * c][i + t], (float)mrow[2 * c + 1][i + t]}, l0[c][t]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l0[c][q] += l1[c][q];   // the higher levels are +0: adding them changes nothing
+  for (; i < R; ++i) {
+    const float v = Mcol[i * R];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+      l0[c][0] = __builtin_elementwise_fma(
+          f32x2_t{v, v}, f32x2_t{(float)mrow[2 * c][i], (float)mrow[2 * c + 1][i]}, l0[c][0]);
+  }
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    l0[c][0] += l0[c][1];
+    l0[c][0] += l0[c][2];
+    l0[c][0] += l0[c][3];
+    out[2 * c] = l0[c][0].x;
+    out[2 * c + 1] = l0[c][0].y;
+  }
+}
+
+// One lane's chain of the canonical norm over its cnt elements, stored contiguously (16-byte
+// aligned).  The chain is serial by definition (one dependent fma per element); the next sixteen
+// operands are read while the current sixteen are consumed.
+__device__ __forceinline__ float norm_chain_rows(const float *__restrict__ x, int cnt) {
+  float acc = 0.f;
+  const int nb = cnt >> 4;
+  f32x4_t A[4], B[4];
+  auto load = [&](f32x4_t (&d)[4], int blk) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4_t *>(x + 16 * blk + 4 * q);
+  };
+  auto eat = [&](const f32x4_t (&d)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __fmaf_rn(d[q][e], d[q][e], acc);
+  };
+  if (nb > 0) load(A, 0);
+  int blk = 0;
+  while (blk + 2 <= nb) {
+    load(B, blk + 1);
+    eat(A);
+    if (blk + 2 < nb) load(A, blk + 2);
+    eat(B);
+    blk += 2;
+  }
+  if (blk < nb) eat(A);
+  for (int k = nb << 4; k < cnt; ++k) acc = __fmaf_rn(x[k], x[k], acc);
+  return acc;
+}
+
+// LDS layout of mpm_fused_kernel, in floats after the control words.  Rows of P and X are padded
+// with zeros to a multiple of four floats, so that every row is read in 16-byte pieces whatever R
+// is (a zero product never changes a maximum that starts at 0); the row stride of P is 4 modulo
+// 8, which spreads the 16-byte pieces of consecutive rows over all banks.
+struct FusedLds {
+  int PS, XS, TS, MB;     // row strides of P and X; lane stride of the norm layout; mask row bytes
+  int off_X, off_M, off_mask, total;
+};
+__host__ __device__ inline FusedLds fused_lds_layout(int R, bool byte_masks) {
+  FusedLds L;
+  const int R4 = (R + 3) & ~3;
+  L.PS = R4 + ((R4 & 7) == 4 ? 0 : 4);
+  L.XS = R4;
+  const int cnt = (R * R) >> 3;                           // elements per lane of the norm
+  L.TS = ((cnt + 27) & ~31) + 4;                          // >= cnt, 4 modulo 32
+  L.MB = (R + 15) & ~15;
+  L.off_X = R * L.PS;
+  L.off_M = L.off_X + R * L.XS;
+  const int m = R * R > 8 * L.TS ? ((R * R + 3) & ~3) : 8 * L.TS;
+  L.off_mask = L.off_M + m;
+  L.total = L.off_mask + (byte_masks ? R * L.MB / 4 : R * ((R + 31) >> 5));
+  return L;
+}
+constexpr int kFusedCtl = 48;   // floats: [0,32) wavefront maxima (two sets), [32] norm, [36,44) norm tail
+
 // NT = work-group size, KMAX = rows per lane (ceil(R / floor(NT / R)) <= KMAX must hold).
+// KMAX <= 8: byte masks, node-similarity factor and previous X in registers.  KMAX = 16 (the
+// largest graphs, whose LDS has no room for byte masks and whose lanes have no registers to
+// spare): A as bit rows, the factor read from global memory at its use, the previous X kept in
+// the caller's X buffer and rewritten every iteration (both stay in L2).
 template <int NT, int KMAX>
 __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
@@ -1097,21 +1383,25 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done,
     int64_t *__restrict__ perm, int n_perm, int32_t *__restrict__ status,
     const int32_t *__restrict__ resume, int r_lo, int r_hi) {
-  // resume != nullptr: only graphs with resume[g] != 0 and r_lo <= R <= r_hi run (one launch per
-  // size class of the kernel), continuing from the X in the caller's buffer after the
-  // iters_done[g] iterations another kernel has already executed
-  if (resume != nullptr &&
-      (resume[blockIdx.x] == 0 || Rarr[blockIdx.x] < r_lo || Rarr[blockIdx.x] > r_hi))
-    return;
-  // control words at the front of the dynamic region (see mpm_stream_kernel): the 128-bit LDS
-  // reads below need its base 16-byte aligned, which a static __shared__ object would undo
+  // a launch serves the graphs of one size class (r_lo <= R <= r_hi): the work-groups of the
+  // others leave at once.  resume != nullptr: only graphs with resume[g] != 0 run, continuing
+  // from the X in the caller's buffer after the iters_done[g] iterations another kernel has
+  // already executed
+  {
+    const int Rg = Rarr[blockIdx.x];
+    if (Rg < r_lo || Rg > r_hi || (resume != nullptr && resume[blockIdx.x] == 0)) return;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
-  float *red = lds_all;                                  // [16]
-  float &s_nrm = lds_all[16];
-  int &s_stop = *reinterpret_cast<int *>(lds_all + 17);
-  float *lds = lds_all + kCtlFloats;
+  float *red = lds_all;                                  // [2][16]
+  float &s_nrm = lds_all[32];
+  float *Ttail = lds_all + 36;                           // [8]
+  float *lds = lds_all + kFusedCtl;
   const int g = blockIdx.x, tid = threadIdx.x;
   constexpr int nt = NT;
+  constexpr bool kRegs = KMAX <= 8;
+  constexpr int NCH = KMAX < 4 ? KMAX : 4;          // chains (rows) a lane advances together
+  constexpr bool kXnRegs = KMAX <= 4;               // the unnormalised new X stays in registers
+  constexpr int kChainUnroll = kXnRegs ? KMAX / NCH : 1;
   const int R = Rarr[g];
   if (R <= 0) {
     if (tid == 0) iters_done[g] = 0;
@@ -1121,59 +1411,88 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     }
     return;
   }
-  const int R2 = R * R, W = (R + 31) >> 5, PS = R + 4;
-  float *Pp = lds;                 // R * (R+4): Pp[a*PS + b] = P[a,b], 0 for a == b
-  float *Xs = Pp + R * PS;         // R*R
-  float *M = Xs + R2;              // R*R
-  uint32_t *Abits = reinterpret_cast<uint32_t *>(M + R2);  // R*W, bit j of row i: A[i,j] != 0, j != i
+  const FusedLds L = fused_lds_layout(R, kRegs);
+  const int R2 = R * R, W = (R + 31) >> 5, PS = L.PS, XS = L.XS, TS = L.TS, MB = L.MB;
+  float *Pp = lds;                 // Pp[a*PS + b] = P[a,b], 0 for a == b and for b >= R
+  float *Xs = lds + L.off_X;       // Xs[j*XS + b] = X[j,b], 0 for b >= R
+  float *M = lds + L.off_M;        // M[j*R + a]; after the column sums the same words hold T
+  float *T = M;                    // T[l*TS + k] = Xn[8k + l] (flat element order), l = 0..7
+  uint8_t *Ab = reinterpret_cast<uint8_t *>(lds + L.off_mask);    // byte masks, rows of MB bytes
+  uint32_t *Abits = reinterpret_cast<uint32_t *>(lds + L.off_mask);  // or bit rows of W words
   const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
   float *Xg = X + g * strideX;
 
-  for (int e = tid; e < R2; e += nt) {
-    const int r = e / R, c = e - r * R;
-    Pp[r * PS + c] = (r == c) ? 0.0f : Pg[(int64_t)r * ld + c];
-    Xs[e] = Xg[(int64_t)r * ldx + c];
+  for (int e = tid; e < R * PS; e += nt) {
+    const int r = e / PS, c = e - r * PS;
+    Pp[e] = (c < R && c != r) ? Pg[(int64_t)r * ld + c] : 0.0f;
   }
-  for (int e = tid; e < R * W; e += nt) {
-    const int r = e / W, w = e - r * W;
-    uint32_t bits = 0;
-    for (int k = 0; k < 32; ++k) {
-      const int c = w * 32 + k;
-      if (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) bits |= (1u << k);
+  for (int e = tid; e < R * XS; e += nt) {
+    const int r = e / XS, c = e - r * XS;
+    Xs[e] = (c < R) ? Xg[(int64_t)r * ldx + c] : 0.0f;
+  }
+  if constexpr (kRegs) {
+    for (int e = tid; e < R * MB; e += nt) {
+      const int r = e / MB, c = e - r * MB;
+      Ab[e] = (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) ? 1 : 0;
     }
-    Abits[e] = bits;
+  } else {
+    for (int e = tid; e < R * W; e += nt) {
+      const int r = e / W, w = e - r * W;
+      uint32_t bits = 0;
+      for (int k = 0; k < 32; ++k) {
+        const int c = w * 32 + k;
+        if (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) bits |= (1u << k);
+      }
+      Abits[e] = bits;
+    }
   }
+  if (tid < 32) red[tid] = 0.f;
   // element ownership for the column sums and the update: lane (ta, tj) owns column a = ta and
-  // rows i = tj + k*TJ; node-similarity factor and previous X of those stay in registers
+  // rows i = tj + k*TJ.  Columns 0..C-1 sum in cascade order, the others as four strands; the
+  // lanes of the first kind come first and the second kind starts at a wavefront boundary when
+  // the work-group has the lanes for it, so that no wavefront (or one) runs both code paths.
   const int TJ = nt / R;
-  const int ta = tid % R, tj = tid / R;
-  const bool owner = tj < TJ;
-  // With 16 rows per lane (1024 threads, 128 registers each) the two arrays do not fit: that
-  // shape reads the node-similarity factor from global memory at its use and keeps the
-  // previous X in the caller's X buffer, rewritten every iteration (both stay in L2).
-  constexpr bool kRegs = KMAX <= 8;
-  constexpr int KR = kRegs ? KMAX : 1;
-  constexpr int kChainUnroll = kRegs ? KMAX / 4 : 1;
-  float nsv[KR], xprev[KR];
+  const int C = (R >= 8) ? (R & ~31) : (R & ~3);
+  const int nA = C * TJ, nB = (R - C) * TJ;
+  const int startB = (((nA + 63) & ~63) + nB <= nt) ? ((nA + 63) & ~63) : nA;
+  bool owner = false;
+  int ta = 0, tj = 0;
+  if (tid < nA) {
+    owner = true;
+    tj = tid / C;
+    ta = tid - tj * C;
+  } else if (tid >= startB && tid < startB + nB) {
+    owner = true;
+    const int u = tid - startB;
+    tj = u / (R - C);
+    ta = C + (u - tj * (R - C));
+  }
+  // registers per lane: previous X (KMAX <= 8); the unnormalised new X and the node-similarity
+  // factor (KMAX <= 4; otherwise the factor is read from global memory at its use, where it
+  // stays in L2)
+  constexpr bool kNsRegs = KMAX <= 4;
+  constexpr int KR = kRegs ? KMAX : 1, KN = kNsRegs ? KMAX : 1, KX = kXnRegs ? KMAX : 1;
+  float nsv[KN], xprev[KR], xn[KX];
   if constexpr (kRegs) {
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       const int i = tj + k * TJ;
-      nsv[k] = 0.f;
-      xprev[k] = 0.f;
-      if (owner && i < R) {
-        nsv[k] = NSg[(int64_t)i * ld + ta];
-        xprev[k] = Xg[(int64_t)i * ldx + ta];
-      }
+      if constexpr (kNsRegs) nsv[k] = (owner && i < R) ? NSg[(int64_t)i * ld + ta] : 0.f;
+      xprev[k] = (owner && i < R) ? Xg[(int64_t)i * ldx + ta] : 0.f;
     }
   }
-  auto ns_of = [&](int k, int i) { return kRegs ? nsv[kRegs ? k : 0] : NSg[(int64_t)i * ld + ta]; };
+  auto ns_of = [&](int k, int i) { return kNsRegs ? nsv[kNsRegs ? k : 0] : NSg[(int64_t)i * ld + ta]; };
   __syncthreads();
 
   const int n8 = R2 & ~7;
   const int JQ = (R + 3) >> 2;          // groups of 4 consecutive rows j
-  const bool vec4 = (R & 3) == 0;
+  const int R4 = XS;
+  // phase-1 items (4 rows x 1 column); while the work-group has at least twice as many lanes,
+  // the b range of an item is cut over 2 or 4 adjacent lanes
+  int split_log2 = 0;
+  while (split_log2 < 2 && ((R * JQ) << (split_log2 + 1)) <= nt) ++split_log2;
   int done = resume != nullptr ? iters_done[g] : 0;
+  int par = 0;
 #ifdef GVAE_FUSED_STAMPS
   long long st_acc[5] = {0, 0, 0, 0, 0}, st_inner = 0;
   long long st_last = __builtin_readcyclecounter();
@@ -1182,98 +1501,122 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     STAMP(4);
     // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b]  (>= 0; Pp[a,a] = 0).  A lane takes one column a
     // and four consecutive rows j at a time: per 4 values of b it reads one 16-byte piece of
-    // Pp's row a and four (wave-broadcast) pieces of X.
+    // Pp's row a and four (wave-broadcast) pieces of X; products in pairs (packed multiply).
 #ifdef GVAE_FUSED_STAMPS
     const long long ti0 = __builtin_readcyclecounter();
 #endif
-    for (int w = tid; w < R * JQ; w += nt) {
-      const int jq = w / R, a = w - jq * R;
-      const int j0 = jq * 4;
-      const float *pr = Pp + a * PS;
-      float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-      const float *x0 = Xs + j0 * R;
-      const float *x1 = Xs + min(j0 + 1, R - 1) * R;
-      const float *x2 = Xs + min(j0 + 2, R - 1) * R;
-      const float *x3 = Xs + min(j0 + 3, R - 1) * R;
-      if (vec4) {
-        for (int b = 0; b < R; b += 4) {
+    auto phase1 = [&](auto sl_tag) {
+      constexpr int SL = decltype(sl_tag)::value;
+      const int part = tid & ((1 << SL) - 1);
+      for (int w = tid >> SL; w < R * JQ; w += nt >> SL) {
+        const int jq = w / R, a = w - jq * R;
+        const int j0 = jq * 4;
+        const float *pr = Pp + a * PS;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        const float *x0 = Xs + j0 * XS;
+        const float *x1 = Xs + min(j0 + 1, R - 1) * XS;
+        const float *x2 = Xs + min(j0 + 2, R - 1) * XS;
+        const float *x3 = Xs + min(j0 + 3, R - 1) * XS;
+        for (int b = 4 * part; b < R4; b += 4 << SL) {
           const f32x4_t p = *reinterpret_cast<const f32x4_t *>(pr + b);
           const f32x4_t a0 = *reinterpret_cast<const f32x4_t *>(x0 + b);
           const f32x4_t a1 = *reinterpret_cast<const f32x4_t *>(x1 + b);
           const f32x4_t a2 = *reinterpret_cast<const f32x4_t *>(x2 + b);
           const f32x4_t a3 = *reinterpret_cast<const f32x4_t *>(x3 + b);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            m0 = fmaxf(m0, p[q] * a0[q]);
-            m1 = fmaxf(m1, p[q] * a1[q]);
-            m2 = fmaxf(m2, p[q] * a2[q]);
-            m3 = fmaxf(m3, p[q] * a3[q]);
-          }
+          f32x2_t q;
+          q = p.lo * a0.lo, m0 = fmaxf(fmaxf(m0, q.x), q.y);
+          q = p.hi * a0.hi, m0 = fmaxf(fmaxf(m0, q.x), q.y);
+          q = p.lo * a1.lo, m1 = fmaxf(fmaxf(m1, q.x), q.y);
+          q = p.hi * a1.hi, m1 = fmaxf(fmaxf(m1, q.x), q.y);
+          q = p.lo * a2.lo, m2 = fmaxf(fmaxf(m2, q.x), q.y);
+          q = p.hi * a2.hi, m2 = fmaxf(fmaxf(m2, q.x), q.y);
+          q = p.lo * a3.lo, m3 = fmaxf(fmaxf(m3, q.x), q.y);
+          q = p.hi * a3.hi, m3 = fmaxf(fmaxf(m3, q.x), q.y);
         }
-      } else {
-        for (int b = 0; b < R; ++b) {
-          const float p = pr[b];
-          m0 = fmaxf(m0, p * x0[b]);
-          m1 = fmaxf(m1, p * x1[b]);
-          m2 = fmaxf(m2, p * x2[b]);
-          m3 = fmaxf(m3, p * x3[b]);
+        // the lanes of an item are adjacent: join their partial maxima (exact in any order)
+        m0 = group_max(m0, SL), m1 = group_max(m1, SL), m2 = group_max(m2, SL), m3 = group_max(m3, SL);
+        if (part == 0) {
+          M[j0 * R + a] = m0;
+          if (j0 + 1 < R) M[(j0 + 1) * R + a] = m1;
+          if (j0 + 2 < R) M[(j0 + 2) * R + a] = m2;
+          if (j0 + 3 < R) M[(j0 + 3) * R + a] = m3;
         }
       }
-      M[j0 * R + a] = m0;
-      if (j0 + 1 < R) M[(j0 + 1) * R + a] = m1;
-      if (j0 + 2 < R) M[(j0 + 2) * R + a] = m2;
-      if (j0 + 3 < R) M[(j0 + 3) * R + a] = m3;
-    }
+    };
+    if (split_log2 == 0)
+      phase1(std::integral_constant<int, 0>{});
+    else if (split_log2 == 1)
+      phase1(std::integral_constant<int, 1>{});
+    else
+      phase1(std::integral_constant<int, 2>{});
 #ifdef GVAE_FUSED_STAMPS
     st_inner += __builtin_readcyclecounter() - ti0;
 #endif
     __syncthreads();
     STAMP(0);
     // phase 2: Xn[i,a] = Xprev[i,a]*NS[i,a] + sum_{j: A[i,j]} M[j,a]  (canonical column sums),
-    // written over Xs
+    // kept in registers until every lane has read M, then stored in the norm's layout over M
+    // (KMAX > 4: in X's own words instead, each rewritten by its owner only)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) xn[k] = 0.f;
     if (owner) {
       const float *Mcol = M + ta;
-      if (column_uses_cascade(ta, R)) {
+      const bool casc = ta < C;
 #pragma unroll kChainUnroll
-        for (int k0 = 0; k0 < KMAX; k0 += 4) {
-          if (tj + k0 * TJ < R) {
-            const uint32_t *br[4];
-            float et[4];
+      for (int k0 = 0; k0 < KMAX; k0 += NCH) {
+        if (tj + k0 * TJ < R) {
+          float et[NCH];
+          if constexpr (kRegs) {
+            const uint8_t *br[NCH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) br[c] = Abits + min(tj + (k0 + c) * TJ, R - 1) * W;
-            cascade_chains<4>(Mcol, R, br, et);
+            for (int c = 0; c < NCH; ++c) br[c] = Ab + min(tj + (k0 + c) * TJ, R - 1) * MB;
+            if (casc)
+              cascade_chains_b<NCH>(Mcol, R, br, et);
+            else
+              ilp4_chains_b<NCH>(Mcol, R, br, et);
+          } else {
+            const uint32_t *br[NCH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int i = tj + (k0 + c) * TJ;
-              // (Xs still holds the previous X here: each element is rewritten by its owner only)
-              if (i < R) Xs[i * R + ta] = Xs[i * R + ta] * ns_of(k0 + c, i) + et[c];
-            }
+            for (int c = 0; c < NCH; ++c) br[c] = Abits + min(tj + (k0 + c) * TJ, R - 1) * W;
+            if (casc)
+              cascade_chains<NCH>(Mcol, R, br, et);
+            else
+              ilp4_chains<NCH>(Mcol, R, br, et);
           }
-        }
-      } else {
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          const int i = tj + k * TJ;
-          if (i < R) {
-            const uint32_t *ab = Abits + i * W;
-            const float et = ilp4_sum(
-                [&](int jj) {
-                  const float v = Mcol[jj * R];
-                  return ((ab[jj >> 5] >> (jj & 31)) & 1u) ? v : 0.0f;
-                },
-                R);
-            Xs[i * R + ta] = Xs[i * R + ta] * ns_of(k, i) + et;
+          for (int c = 0; c < NCH; ++c) {
+            const int i = tj + (k0 + c) * TJ;
+            if (i < R) {
+              const float val = Xs[i * XS + ta] * ns_of(k0 + c, i) + et[c];
+              if constexpr (kXnRegs)
+                xn[k0 + c] = val;
+              else
+                Xs[i * XS + ta] = val;
+            }
           }
         }
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = tj + k * TJ;
+      if (owner && i < R) {
+        const int e = i * R + ta;
+        const float val = kXnRegs ? xn[kXnRegs ? k : 0] : Xs[i * XS + ta];
+        if (e < n8)
+          T[(e & 7) * TS + (e >> 3)] = val;
+        else
+          Ttail[e - n8] = val;
+      }
+    }
+    __syncthreads();
     STAMP(1);
-    // phase 3: canonical norm over the contiguous R*R block
+    // phase 3: canonical norm over the R*R elements in flat order
     if (tid < 64) {
       float acc = 0.f;
-      if (tid < 8) acc = norm_chain(Xs, n8, tid, acc);
-      const float nrm = norm_finish(acc, Xs + n8, R2 - n8);
+      if (tid < 8) acc = norm_chain_rows(T + tid * TS, n8 >> 3);
+      const float nrm = norm_finish(acc, Ttail, R2 - n8);
       if (tid == 0) s_nrm = nrm;
     }
     __syncthreads();
@@ -1285,7 +1628,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     for (int k = 0; k < KMAX; ++k) {
       const int i = tj + k * TJ;
       if (owner && i < R) {
-        const float v = Xs[i * R + ta] / nrm;
+        const float v = (kXnRegs ? xn[kXnRegs ? k : 0] : Xs[i * XS + ta]) / nrm;
         float prev;
         if constexpr (kRegs) {
           prev = xprev[k];
@@ -1297,22 +1640,25 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
         const float d = fabsf(v - prev);
         isnan_any |= (d != d);
         dmax = fmaxf(dmax, d);
-        Xs[i * R + ta] = v;
+        Xs[i * XS + ta] = v;
       }
     }
     if (isnan_any) dmax = INFINITY;
-    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = dmax;
+    dmax = wave_max(dmax);
+    if ((tid & 63) == 0) red[par * 16 + (tid >> 6)] = dmax;
     __syncthreads();
-    if (tid == 0) {
-      float d = red[0];
-      for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
-      s_stop = (early_stop && d < tol) ? 1 : 0;
+    // every lane folds the wavefronts' maxima itself (the set alternates between iterations, so
+    // a lane still reading this one cannot meet the next one's writes)
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < (NT >> 6); q += 4) {
+      const f32x4_t r4 = *reinterpret_cast<const f32x4_t *>(red + par * 16 + q);
+      d = fmaxf(fmaxf(d, fmaxf(r4.x, r4.y)), fmaxf(r4.z, r4.w));
     }
-    __syncthreads();
+    par ^= 1;
     STAMP(3);
     ++done;
-    if (s_stop) break;
+    if (early_stop && d < tol) break;
   }
 #ifdef GVAE_FUSED_STAMPS
   if (g == 0 && tid == 0)
@@ -1328,12 +1674,11 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   }
   if (tid == 0) iters_done[g] = done;
   // Epilogue (perm != nullptr): the assignment of this graph, by the first wavefront, straight
-  // from the X in LDS (row stride R, what the solver expects).  A graph that converges early
-  // starts its assignment early; as a separate launch the assignments start only after the
-  // slowest graph's last MPM iteration.
+  // from the X in LDS.  A graph that converges early starts its assignment early; as a separate
+  // launch the assignments start only after the slowest graph's last MPM iteration.
   if (perm != nullptr) {
     __syncthreads();               // the last iteration's Xs (iters == 0: the initial X)
-    if (tid < 64) lsap_wave(Xs, R, R, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
+    if (tid < 64) lsap_wave(Xs, R, XS, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
   }
 }
 
@@ -1455,10 +1800,10 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
 static int64_t g_handoff_bytes = 128LL << 20;
 #define GVAE_HANDOFF_MAX_NODES 32
 
-// control words | P (rows of R + 4 floats) | X | M | bit rows of A
+// control words + the layout of fused_lds_layout for the largest graph of the launch's size class
+constexpr int kFusedByteMaskMaxNodes = 88;      // classes served by the KMAX <= 8 kernel shapes
 static inline size_t mpm_fused_lds_bytes(int r_max) {
-  return 4 * kCtlFloats + 12 * (size_t)r_max * r_max + 16 * (size_t)r_max +
-         4 * (size_t)r_max * ((r_max + 31) / 32);
+  return sizeof(float) * (size_t)(kFusedCtl + fused_lds_layout(r_max, r_max <= kFusedByteMaskMaxNodes).total);
 }
 constexpr size_t kMaxFusedLds = kMaxDynLds;
 static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
@@ -1707,7 +2052,7 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "%s: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d)", who, n_graphs, r_max, ld, ldx);
   size_t lds = mpm_fused_lds_bytes(r_max);
-  int r_lo = 0, r_hi = r_max;
+  int r_lo = INT32_MIN, r_hi = r_max;
   GVAE_REQUIRE(r_max <= GVAE_MAX_NODES_LDS && lds <= kMaxFusedLds, GVAE_ELIMIT,
                "%s: r_max=%d needs %zu bytes of LDS (limit 160 KiB)", who, r_max, lds);
   if (n_graphs == 0) return GVAE_OK;
@@ -1726,8 +2071,12 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
     return GVAE_OK;
   };
   auto pick = [&](int rm) -> int {
-    if (rm <= 32) return launch(mpm_fused_kernel<256, 4>, 256);
-    if (rm <= 64) return launch(mpm_fused_kernel<512, 8>, 512);
+    // rows per lane = ceil(R / floor(NT / R)) must not exceed KMAX
+    if (rm <= 16) return launch(mpm_fused_kernel<256, 4>, 256);
+    if (rm <= 32) return launch(mpm_fused_kernel<512, 2>, 512);
+    if (rm <= 44) return launch(mpm_fused_kernel<512, 4>, 512);
+    if (rm <= 64) return launch(mpm_fused_kernel<1024, 4>, 1024);
+    if (rm <= kFusedByteMaskMaxNodes) return launch(mpm_fused_kernel<1024, 8>, 1024);
     return launch(mpm_fused_kernel<1024, 16>, 1024);
   };
   int rc = GVAE_OK;
@@ -1736,8 +2085,8 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
   } else {
     // resumed graphs: each by the kernel shape of its own size class (work-groups of graphs
     // outside the class, or not handed over, leave at once)
-    const int hi[3] = {32, 64, GVAE_MAX_NODES_LDS};
-    for (int c = 0, lo = 1; c < 3 && !rc && lo <= r_max; lo = hi[c] + 1, ++c) {
+    const int hi[5] = {32, 44, 64, kFusedByteMaskMaxNodes, GVAE_MAX_NODES_LDS};
+    for (int c = 0, lo = 1; c < 5 && !rc && lo <= r_max; lo = hi[c] + 1, ++c) {
       r_lo = lo;
       r_hi = r_max < hi[c] ? r_max : hi[c];
       lds = mpm_fused_lds_bytes(r_hi);

@@ -166,15 +166,23 @@ def enzymes_like_sizes(n: int, rng: np.random.Generator, lo: int = 2, hi: int = 
 
 def synthetic_adjacencies(kind: str, n_graphs: int, max_nodes: int, seed: int = 0) -> list:
     """kind = "dense": R = max_nodes, Erdos-Renyi p = 0.5.
-    kind = "enzymes": ENZYMES-shaped sizes, ER with mean degree ~3.8 (>= 1 edge per node)."""
+    kind = "enzymes": ENZYMES-shaped sizes, ER with mean degree ~3.8 (>= 1 edge per node).
+    kind = "enzymes_filtered": the same with sizes drawn over the full 2..126 range and graphs
+    above max_nodes dropped, as the reference's loader drops them (train_ddp.py:147)."""
     rng = np.random.default_rng(seed)
     out = []
     if kind == "dense":
         sizes = np.full(n_graphs, max_nodes)
     elif kind == "enzymes":
         sizes = enzymes_like_sizes(n_graphs, rng, 2, max_nodes)
+    elif kind == "enzymes_filtered":
+        kept = np.zeros(0, np.int64)
+        while kept.size < n_graphs:
+            draw = enzymes_like_sizes(2 * n_graphs, rng, 2, 126)
+            kept = np.concatenate([kept, draw[draw <= max_nodes]])
+        sizes = kept[:n_graphs]
     else:
-        raise ValueError("kind must be 'dense' or 'enzymes'")
+        raise ValueError("kind must be 'dense', 'enzymes' or 'enzymes_filtered'")
     for R in sizes.tolist():
         p = 0.5 if kind == "dense" else min(1.0, 3.8 / max(R - 1, 1))
         up = np.triu(rng.random((R, R)) < p, 1)
