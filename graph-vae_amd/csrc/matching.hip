@@ -317,7 +317,7 @@ __device__ __forceinline__ void row_step_reduce(const RowStep<LPR_LOG2, PASSES, 
   }
 }
 
-template <int LPR_LOG2, int PASSES, int RB>
+template <int LPR_LOG2, int PASSES, int RB, bool TWO = false>
 __device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab, int R, int RS,
                                                  int a0, int Aw, const float *Xs, float *T) {
   constexpr int LPR = 1 << LPR_LOG2;
@@ -336,16 +336,32 @@ __device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab,
   // One buffer of RB*PASSES loads per lane.  Measured against a second buffer with the next
   // step's loads in flight during the reduction: no gain at 32 nodes, 10 % slower at 64 (HBM
   // does not reward more than about 64 KiB outstanding per compute unit).
+  // TWO: a launch whose LDS footprint leaves one work-group per compute unit has nobody else to
+  // cover the round trip of a step's loads, so the next step's loads are issued before the
+  // current step is reduced.
   RowStep<LPR_LOG2, PASSES, RB> A;
-  for (int base = 0; base < NR; base += step) {
-    row_step_issue(A, slab, R, RS, a0, Aw, inv_aw, NR, base + grp, rpp, coff);
-    row_step_reduce(A, Xs, T, coff);
+  if constexpr (!TWO) {
+    for (int base = 0; base < NR; base += step) {
+      row_step_issue(A, slab, R, RS, a0, Aw, inv_aw, NR, base + grp, rpp, coff);
+      row_step_reduce(A, Xs, T, coff);
+    }
+  } else {
+    RowStep<LPR_LOG2, PASSES, RB> B;
+    row_step_issue(A, slab, R, RS, a0, Aw, inv_aw, NR, grp, rpp, coff);
+    for (int base = 0; base < NR; base += 2 * step) {
+      const bool hasB = base + step < NR;
+      if (hasB) row_step_issue(B, slab, R, RS, a0, Aw, inv_aw, NR, base + step + grp, rpp, coff);
+      row_step_reduce(A, Xs, T, coff);
+      if (base + 2 * step < NR)
+        row_step_issue(A, slab, R, RS, a0, Aw, inv_aw, NR, base + 2 * step + grp, rpp, coff);
+      if (hasB) row_step_reduce(B, Xs, T, coff);
+    }
   }
 }
 
 // picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
-template <int V>
+template <int V, bool TWO = false>
 __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R, int RS,
                                                   int a0, int Aw, const float *Xs, float *T) {
   const int cols = RS / V;
@@ -359,14 +375,14 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
     // every shape up to 35 vectors per row (R <= 140, the LDS limit of the kernel)
     const int key = lpr_log2 * 8 + passes;
     switch (key) {
-      case 0 * 8 + 1: return mpm_iter_body_v4<0, 1, D>(slab, R, RS, a0, Aw, Xs, T);
-      case 1 * 8 + 1: return mpm_iter_body_v4<1, 1, D>(slab, R, RS, a0, Aw, Xs, T);
-      case 2 * 8 + 1: return mpm_iter_body_v4<2, 1, D>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 1: return mpm_iter_body_v4<3, 1, D>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, (D + 1) / 2>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4>(slab, R, RS, a0, Aw, Xs, T);
-      case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3>(slab, R, RS, a0, Aw, Xs, T);
+      case 0 * 8 + 1: return mpm_iter_body_v4<0, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 1 * 8 + 1: return mpm_iter_body_v4<1, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 2 * 8 + 1: return mpm_iter_body_v4<2, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 1: return mpm_iter_body_v4<3, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
       default: break;
     }
   }
@@ -516,6 +532,7 @@ struct MpmQueue {
   int32_t *words;             // [0] head  [32] tail  [64] remaining graphs  [65] their slab KiB  [96] error
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
+  int two_buffers;            // one work-group per compute unit: two steps of loads in flight
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
   // Hand-off of the latency-bound tail (gvae_match_stream only; handoff == nullptr: never).  Once
@@ -671,10 +688,19 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       // X was written by another work-group of this launch (write-through stores, drained
       // before the item was pushed): read it past this CU's vector cache, which is the only
       // cache another CU's stores do not reach
-      for (int e = tid; e < R * RS; e += nt) {
-        const int r = e / RS, c = e - r * RS;
-        Xs[e] = __hip_atomic_load(&Xg[(int64_t)r * ldx + min(c, R - 1)], __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
+      // (four loads in flight per lane: each is a round trip to L2)
+      for (int e0 = tid; e0 < R * RS; e0 += 4 * nt) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = min(e0 + u * nt, R * RS - 1);
+          const int r = e / RS, c = e - r * RS;
+          v[u] = __hip_atomic_load(&Xg[(int64_t)r * ldx + min(c, R - 1)], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e0 + u * nt < R * RS) Xs[e0 + u * nt] = v[u];
       }
       // S[i,i,a,a], the factor of X[i,a] in the update, for every row i of the item: a strided
       // gather that shares the round trip of the X loads
@@ -695,7 +721,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         const float *slab = Sg + (int64_t)i * R2 * RS;
         const float *nsr = nsrow + ri * R;
         SSTAMP(1);
-        if ((RS & 3) == 0) mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
+        if ((RS & 3) == 0) {
+          if (q.two_buffers) mpm_iter_dispatch<4, true>(slab, R, RS, a0, Aw, Xs, T);
+          else mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
+        }
         else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
         else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
         __syncthreads();
@@ -729,8 +758,16 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
 #endif
         // ---- last arriver: normalise the graph
         // (the other producers' rows: write-through stores, read past the vector cache)
-        for (int e = tid; e < R2; e += nt)
-          T[e] = __hip_atomic_load(&Xn[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e0 = tid; e0 < R2; e0 += 4 * nt) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            v[u] = __hip_atomic_load(&Xn[min(e0 + u * nt, R2 - 1)], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (e0 + u * nt < R2) T[e0 + u * nt] = v[u];
+        }
         __syncthreads();
         SSTAMP(5);
         const int n8 = R2 & ~7;
@@ -755,7 +792,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_store(&Xg[(int64_t)r * ldx + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        dmax = wave_max(dmax);
         if ((tid & 63) == 0) red[tid >> 6] = dmax;
         __syncthreads();
         if (tid == 0) {
@@ -1798,7 +1835,9 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
 // (0: never).  128 MiB: one pass at the streaming rate of 6.7 TB/s takes 19 us, the latency of
 // one iteration's chain of dependent steps in the queue kernel.
 static int64_t g_handoff_bytes = 128LL << 20;
-#define GVAE_HANDOFF_MAX_NODES 32
+#ifndef GVAE_HANDOFF_MAX_NODES
+#define GVAE_HANDOFF_MAX_NODES 88
+#endif
 
 // control words + the layout of fused_lds_layout for the largest graph of the launch's size class
 constexpr int kFusedByteMaskMaxNodes = 88;      // classes served by the KMAX <= 8 kernel shapes
@@ -1873,11 +1912,13 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // items: ENZYMES-shaped batch (64 graphs up to 126 nodes) 4.89 ms at 1024, 4.46 ms at 256.
   q.low = nt == 1024 ? 256 : 1024;
   q.high = 4096;
+  q.two_buffers = 2 * (lds + 1024) > 160 * 1024;      // LDS leaves room for one work-group per CU
 #ifdef GVAE_TUNE
   // tuning builds only: launch shape and item-shape thresholds from the environment
   if (const char *e = getenv("GVAE_MPM_NT")) nt = atoi(e);
   if (const char *e = getenv("GVAE_MPM_LOW")) q.low = atoi(e);
   if (const char *e = getenv("GVAE_MPM_HIGH")) q.high = atoi(e);
+  if (const char *e = getenv("GVAE_MPM_TWO")) q.two_buffers = atoi(e);
 #endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
@@ -2030,9 +2071,9 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
   // Graphs small enough for the S-free kernel may be handed to it once the batch is bound by
   // the latency of an iteration rather than by HBM (see MpmQueue): same X, same iteration
   // counts, bit for bit, whichever kernel runs an iteration.
-  // Only graphs of at most 32 nodes: there an S-free iteration takes 5 us against the 19 us of
-  // the queue kernel's chain; from 33 nodes on the S-free kernel needs 18 us and more per
-  // iteration (one work-group per graph), which is no faster than streaming.
+  // Only graphs of at most 88 nodes (the size classes of the S-free kernel that keep byte masks):
+  // there an S-free iteration takes 5 us (32 nodes) to 34 us (88), less than the chain of one
+  // streamed iteration of a graph that has the device to itself (19 us + its slab's transfer).
   const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
   const bool handoff = early_stop && g_handoff_bytes > 0 && r_cap > 0;
   rc = mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,

@@ -442,7 +442,7 @@ def test_match_stream_tail_handoff(hip):
     form exists) is never handed off; the workspace counters say what the streaming kernel ran."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(23)
-    sizes = (32, 31, 17, 40, 9, 64, 33, 2, 25, 48, 12, 70)
+    sizes = (32, 31, 17, 40, 9, 64, 33, 2, 25, 48, 12, 70, 88, 89, 96)
     As, Ps = [], []
     for k, R in enumerate(sizes):
         w = (rng.random((R, R)) < 0.35).astype(np.float32)
@@ -478,9 +478,9 @@ def test_match_stream_tail_handoff(hip):
             streamed[name] = hip.mpm_stream_stats(ws.data_ptr())
         # iteration 1 comes from the first-iteration kernel; the rest was streamed ...
         assert streamed["off"] == (int((per_gi * (it - 1)).sum()), int((it - 1).sum()))
-        # ... or, handed off at once, one streamed iteration per graph of at most 32 nodes that
+        # ... or, handed off at once, one streamed iteration per graph of at most 88 nodes that
         # needed a second one (larger graphs and the weighted graph are never handed off)
-        keep = (np.arange(len(Rh)) == 4) | (r > 32)
+        keep = (np.arange(len(Rh)) == 4) | (r > 88)
         one = np.where(keep, it - 1, np.minimum(it - 1, 1))
         assert streamed["always"] == (int((per_gi * one).sum()), int(one.sum()))
         assert streamed["always"][1] <= streamed["default"][1] <= streamed["off"][1]
