@@ -773,6 +773,113 @@ int launch_loss_fwd(const float *vec, const float *node, const float *adj, const
   return check_launch("loss_fwd");
 }
 
+// The older per-graph-density loss (reference model_legacy.py:312-352): pairs r < c < R of the
+// PERMUTED ground truth against the prediction in place; pos_weight = clamp((1 - rho) /
+// (rho + 1e-8), 1, 20) with rho = positives / (R(R-1)/2 + 1e-8) of this graph; no node term.
+// The weight is kept per graph for the backward.
+__global__ __launch_bounds__(256) void loss_fwd_indiv_kernel(
+    const float *__restrict__ vec, const float *__restrict__ adj, const float *__restrict__ mu,
+    const float *__restrict__ lvraw, const int64_t *__restrict__ perm,
+    const int32_t *__restrict__ Rarr, int N, int Z, float *__restrict__ rec_i,
+    float *__restrict__ kl_i, float *__restrict__ maxlogit_i, float *__restrict__ pw_i) {
+  __shared__ float sh[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int R = Rarr[g], U = N * (N - 1) / 2;
+  const float *vg = vec + (int64_t)g * U;
+  const float *Ag = adj + (int64_t)g * N * N;
+  const int64_t *pg = perm + (int64_t)g * N;
+  const int npairs = R * (R - 1) / 2;
+  auto pair_of = [&](int t, int &r, int &c) {
+    r = (int)((2.0f * R - 1.0f - sqrtf((2.0f * R - 1.0f) * (2.0f * R - 1.0f) - 8.0f * t)) * 0.5f);
+    while (r > 0 && r * R - (r * (r + 1)) / 2 > t) --r;
+    while ((r + 1) * R - ((r + 1) * (r + 2)) / 2 <= t) ++r;
+    c = t - (r * R - (r * (r + 1)) / 2) + r + 1;
+  };
+  float s = 0.0f;
+  for (int t = tid; t < npairs; t += 256) {
+    int r, c;
+    pair_of(t, r, c);
+    s += Ag[pg[r] * N + pg[c]];
+  }
+  const float pos = block_sum_256(s, sh);                  // a count: exact
+  const float rho = pos / (float)((double)npairs + 1e-8);
+  const float pw = fminf(fmaxf((1.0f - rho) / (rho + 1e-8f), 1.0f), 20.0f);
+  s = 0.0f;
+  for (int t = tid; t < npairs; t += 256) {
+    int r, c;
+    pair_of(t, r, c);
+    s += bce_logits(vg[tri_index(r, c, N)], Ag[pg[r] * N + pg[c]], pw);
+  }
+  const float edge = block_sum_256(s, sh) / (float)npairs;
+  s = 0.0f;
+  for (int k = tid; k < Z; k += 256) {
+    const float m = mu[(int64_t)g * Z + k];
+    const float lv = fminf(fmaxf(lvraw[(int64_t)g * Z + k], -4.0f), 4.0f);
+    s += 1.0f + lv - m * m - expf(lv);
+  }
+  const float kl = -0.5f * (block_sum_256(s, sh) / (float)Z);
+  float mx = 0.0f;
+  for (int t = tid; t < U; t += 256) mx = fmaxf(mx, fabsf(vg[t]));
+  mx = block_max_256(mx, sh);
+  if (tid == 0) {
+    rec_i[g] = edge;
+    kl_i[g] = kl;
+    maxlogit_i[g] = mx;
+    pw_i[g] = pw;
+  }
+}
+
+int launch_loss_fwd_indiv(const float *vec, const float *adj, const float *mu, const float *lvraw,
+                          const int64_t *perm, const int32_t *R, int B, int N, int Z, float *rec_i,
+                          float *kl_i, float *maxlogit_i, float *pw_i, float *out4, hipStream_t s) {
+  hipLaunchKernelGGL(loss_fwd_indiv_kernel, dim3(B), dim3(256), 0, s, vec, adj, mu, lvraw, perm, R, N,
+                     Z, rec_i, kl_i, maxlogit_i, pw_i);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, rec_i, kl_i, maxlogit_i, lvraw, B,
+                     Z, out4);
+  return check_launch("loss_fwd_indiv");
+}
+
+// its gradient: dvec[g,(a,b)] = cr/npairs * ((1-y) - lw*(1-sigmoid(x))), y = A[perm a, perm b],
+// for a < b < R, else 0; the node head gets none
+__global__ void loss_bwd_indiv_kernel(const float *__restrict__ vec, const float *__restrict__ adj,
+                                      const int32_t *__restrict__ Rarr,
+                                      const int64_t *__restrict__ perm,
+                                      const float *__restrict__ pw_i, int N, float cr,
+                                      const float *__restrict__ d_up, float *__restrict__ dvec,
+                                      float *__restrict__ dnode) {
+  const int g = blockIdx.y;
+  const int R = Rarr[g], U = N * (N - 1) / 2;
+  if (d_up) cr *= d_up[0];
+  const float pw = pw_i[g];
+  const float inv_pairs = 1.0f / (float)(R * (R - 1) / 2);
+  const float *Ag = adj + (int64_t)g * N * N;
+  const int64_t *pg = perm + (int64_t)g * N;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += gridDim.x * blockDim.x) {
+    const int a = e / N, b = e - a * N;
+    if (a < b) {
+      const int t = tri_index(a, b, N);
+      float gr = 0.0f;
+      if (b < R) {
+        const float x = vec[(int64_t)g * U + t], y = Ag[pg[a] * N + pg[b]];
+        const float lw = 1.0f + (pw - 1.0f) * y;
+        const float sg = 1.0f / (1.0f + expf(-x));
+        gr = cr * inv_pairs * ((1.0f - y) - lw * (1.0f - sg));
+      }
+      dvec[(int64_t)g * U + t] = gr;
+    } else if (a == b) {
+      dnode[(int64_t)g * N + a] = 0.0f;
+    }
+  }
+}
+
+int launch_loss_bwd_indiv(const float *vec, const float *adj, const int32_t *R, const int64_t *perm,
+                          const float *pw_i, int B, int N, float c_rec, const float *d_up, float *dvec,
+                          float *dnode, hipStream_t s) {
+  hipLaunchKernelGGL(loss_bwd_indiv_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s,
+                     vec, adj, R, perm, pw_i, N, c_rec / (float)B, d_up, dvec, dnode);
+  return check_launch("loss_bwd_indiv");
+}
+
 // d(rec)/d(logits).  rec = mean_g (edge_g + node_g); the edge mean runs over all
 // unordered pairs of real nodes, each exactly once whatever the permutation, so
 //   dvec[g,(a,b)] = cr/npairs * ((1-y) - lw*(1-sigmoid(x)))   for a < b < R, else 0

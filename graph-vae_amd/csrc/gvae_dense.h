@@ -93,5 +93,11 @@ int launch_loss_fwd(const float *vec, const float *node, const float *adj, const
 int launch_loss_bwd(const float *vec, const float *node, const float *adj, const int32_t *R, int B,
                     int N, const float *pos_weight, int mask_dummy, float c_rec, const float *d_up,
                     float *dvec, float *dnode, hipStream_t s);
+int launch_loss_fwd_indiv(const float *vec, const float *adj, const float *mu, const float *lvraw,
+                          const int64_t *perm, const int32_t *R, int B, int N, int Z, float *rec_i,
+                          float *kl_i, float *maxlogit_i, float *pw_i, float *out4, hipStream_t s);
+int launch_loss_bwd_indiv(const float *vec, const float *adj, const int32_t *R, const int64_t *perm,
+                          const float *pw_i, int B, int N, float c_rec, const float *d_up, float *dvec,
+                          float *dnode, hipStream_t s);
 
 }  // namespace gvae

@@ -41,6 +41,11 @@ struct Workspace {
   int64_t splitk_floats;
   int32_t *status;
   int32_t *bn_mode;   // [0]: the forward of this batch normalised with batch statistics
+  // GVAE_LOSS_INDIVIDUAL_RHO: node count N for every graph (the matching runs over all rows),
+  // the per-graph positive weight and the permutation as the forward left them for the backward
+  int32_t *r_full;
+  float *pw_i;
+  int64_t *perm_fwd;
   char *mpm_ws;
   int64_t bytes;
 };
@@ -81,6 +86,9 @@ static Workspace carve(const gvae_dims *d, int B, char *base) {
   w.splitk = take(w.splitk_floats);
   w.status = reinterpret_cast<int32_t *>(take(B));
   w.bn_mode = reinterpret_cast<int32_t *>(take(4));
+  w.r_full = reinterpret_cast<int32_t *>(take(B));
+  w.pw_i = take(B);
+  w.perm_fwd = reinterpret_cast<int64_t *>(take(2 * (int64_t)B * N));
   w.mpm_ws = reinterpret_cast<char *>(take((gvae_mpm_stream_ws_bytes(B, (int)N) + 3) / 4));
   w.bytes = off;
   return w;
@@ -170,6 +178,11 @@ __global__ void x0_init_kernel(const int32_t *__restrict__ Rarr, int N, float *_
     const int i = e / N, a = e - i * N;
     X[(int64_t)g * N * N + e] = (i < R && a < R) ? v : 0.0f;
   }
+}
+
+__global__ void fill_i32_kernel(int32_t *a, int n, int32_t v) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) a[e] = v;
 }
 
 __global__ void identity_perm_kernel(int64_t *perm, int B, int N) {
@@ -351,6 +364,14 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
   const int B = n_graphs, Z = d->Z, N = d->N;
   const Workspace w = carve(d, B, (char *)d_ws);
   const bool do_match = phases & GVAE_PHASE_MATCH, do_assign = phases & GVAE_PHASE_ASSIGN_LOSS;
+  // model_legacy.py:294-310 matches all N rows of the padded matrices (no cut to the real nodes)
+  const bool indiv = loss_variant == GVAE_LOSS_INDIVIDUAL_RHO;
+  const int32_t *d_R_loss = d_R;
+  if (indiv) {
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, w.r_full, B, N);
+    d_R = w.r_full;
+    r_max = N;
+  }
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
     if (do_match) {
@@ -389,6 +410,13 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
   // assignment (model.py:319-323), unless the S-free MPM above has already done it
   if (matching == GVAE_MATCH_STREAM || (matching == GVAE_MATCH_FUSED && !do_match))
     TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
+  if (indiv) {
+    TRY(launch_loss_fwd_indiv(w.vec, d_adj, w.mu, w.lvraw, d_perm, d_R_loss, B, N, Z, w.rec_i, w.kl_i,
+                              w.maxlogit_i, w.pw_i, d_out4, s));
+    TRY(hipMemcpyAsync(w.perm_fwd, d_perm, sizeof(int64_t) * (size_t)B * N, hipMemcpyDeviceToDevice,
+                       s) == hipSuccess ? 0 : GVAE_ELAUNCH);
+    return 0;
+  }
   // losses (model.py:325-373)
   TRY(launch_loss_fwd(w.vec, w.node, d_adj, w.mu, w.lvraw, d_perm, d_R, B, N, Z, d_pos_weight,
                       loss_variant == GVAE_LOSS_DUMMY_MASKED, w.rec_i, w.kl_i, w.maxlogit_i, d_out4, s));
@@ -402,8 +430,11 @@ static int check_match_args(const gvae_dims *d, int n_graphs, int r_max, int los
                "%s: bad sizes (n_graphs=%d r_max=%d N=%d)", who, n_graphs, r_max, d->N);
   GVAE_REQUIRE(matching >= GVAE_MATCH_NONE && matching <= GVAE_MATCH_FUSED, GVAE_EINVAL,
                "%s: unknown matching mode %d", who, matching);
-  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
+  GVAE_REQUIRE(loss_variant >= GVAE_LOSS_CURRENT && loss_variant <= GVAE_LOSS_INDIVIDUAL_RHO,
                GVAE_EINVAL, "%s: unknown loss variant %d", who, loss_variant);
+  GVAE_REQUIRE(loss_variant != GVAE_LOSS_INDIVIDUAL_RHO || (r_max == d->N && matching != GVAE_MATCH_NONE),
+               GVAE_EINVAL, "%s: the individual-rho loss matches all N=%d rows (r_max=%d) and needs a matching",
+               who, d->N, r_max);
   GVAE_REQUIRE(matching != GVAE_MATCH_STREAM || (d_S && d_S_off), GVAE_EINVAL,
                "%s: streaming matching needs the S buffer and its offsets", who);
   GVAE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || h_chunk_begin), GVAE_EINVAL, "%s: bad chunk list",
@@ -479,7 +510,7 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
                GVAE_EINVAL, "step_backward: null pointer");
   GVAE_REQUIRE(n_graphs > 0 && n_graphs <= 65535, GVAE_EINVAL, "step_backward: bad n_graphs=%d",
                n_graphs);
-  GVAE_REQUIRE(loss_variant == GVAE_LOSS_CURRENT || loss_variant == GVAE_LOSS_DUMMY_MASKED,
+  GVAE_REQUIRE(loss_variant >= GVAE_LOSS_CURRENT && loss_variant <= GVAE_LOSS_INDIVIDUAL_RHO,
                GVAE_EINVAL, "step_backward: unknown loss variant %d", loss_variant);
   hipStream_t s = (hipStream_t)stream;
   const int B = n_graphs, F = d->F, H = d->H, Z = d->Z, N = d->N, U = N * (N - 1) / 2;
@@ -489,8 +520,12 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
   param_layout(d, off, nullptr);
   auto G = [&](int i) { return d_grads + off[i]; };
 
-  TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight,
-                      loss_variant == GVAE_LOSS_DUMMY_MASKED, c_rec, d_up, w.dvec, w.dnode, s));
+  if (loss_variant == GVAE_LOSS_INDIVIDUAL_RHO)
+    TRY(launch_loss_bwd_indiv(w.vec, d_adj, d_R, w.perm_fwd, w.pw_i, B, N, c_rec, d_up, w.dvec,
+                              w.dnode, s));
+  else
+    TRY(launch_loss_bwd(w.vec, w.node, d_adj, d_R, B, N, d_pos_weight,
+                        loss_variant == GVAE_LOSS_DUMMY_MASKED, c_rec, d_up, w.dvec, w.dnode, s));
   // edge and node heads, layer by layer: the four contractions of a layer are independent
   {
     GemmDesc l2[4] = {

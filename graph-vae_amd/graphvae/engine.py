@@ -16,7 +16,7 @@ from .data import DenseGraphBatch
 P_COUNT = 20
 MATCH_NONE, MATCH_STREAM, MATCH_FUSED = 0, 1, 2
 _MATCH = {"none": MATCH_NONE, "stream": MATCH_STREAM, "fused": MATCH_FUSED}
-LOSS_CURRENT, LOSS_DUMMY_MASKED = 0, 1   # GVAE_LOSS_* of the library
+LOSS_CURRENT, LOSS_DUMMY_MASKED, LOSS_INDIVIDUAL_RHO = 0, 1, 2   # GVAE_LOSS_* of the library
 PHASE_MATCH, PHASE_ASSIGN_LOSS = 1, 2    # GVAE_PHASE_* of the library
 
 # parameter tensors in flat-buffer order (reference module named_parameters() order)
@@ -230,15 +230,23 @@ class StepEngine:
         _hip._dev(eps, torch.float32), _hip._dev(pos_weight, torch.float32)
         if tuple(eps.shape) != (B, self.Z):
             raise _hip.GvaeHipError(f"eps must be ({B}, {self.Z})")
-        if loss_variant not in (LOSS_CURRENT, LOSS_DUMMY_MASKED):
+        if loss_variant not in (LOSS_CURRENT, LOSS_DUMMY_MASKED, LOSS_INDIVIDUAL_RHO):
             raise ValueError(f"unknown loss variant {loss_variant}")
-        r_max = max(batch.r_host)
-        return B, r_max, self.resolve_matching(r_max)
+        r_max = max(self._matched_sizes(batch, loss_variant))
+        mode = self.resolve_matching(r_max)
+        if loss_variant == LOSS_INDIVIDUAL_RHO and mode == MATCH_NONE:
+            raise _hip.GvaeHipError("the individual-rho loss needs a matching (its loss depends on the permutation)")
+        return B, r_max, mode
 
-    def _S_args(self, mode: int, batch: DenseGraphBatch):
+    def _matched_sizes(self, batch: DenseGraphBatch, loss_variant: int):
+        """Node counts the matching runs over: the real nodes, or all max_nodes rows for the
+        individual-rho loss (reference model_legacy.py:294-300)."""
+        return (self.N,) * batch.num_graphs if loss_variant == LOSS_INDIVIDUAL_RHO else batch.r_host
+
+    def _S_args(self, mode: int, batch: DenseGraphBatch, loss_variant: int = LOSS_CURRENT):
         if mode != MATCH_STREAM:
             return None, None, None, 0
-        self._ensure_S(batch.r_host)
+        self._ensure_S(self._matched_sizes(batch, loss_variant))
         # the shared buffers are used on whichever stream runs the matching: the allocator must
         # not hand their memory out again while that stream still reads it
         cur = torch.cuda.current_stream(self.device)
@@ -251,10 +259,11 @@ class StepEngine:
                 loss_variant: int = LOSS_CURRENT) -> torch.Tensor:
         """Runs the forward; returns the device tensor [rec, kl, max_logit, logvar_max]
         (a view of engine memory, overwritten by the next forward).  `loss_variant`:
-        LOSS_CURRENT (reference model.py:281-373) or LOSS_DUMMY_MASKED (`forward_old`,
-        model.py:378-440); the backward of this batch uses the same variant."""
+        LOSS_CURRENT (reference model.py:281-373), LOSS_DUMMY_MASKED (`forward_old`,
+        model.py:378-440) or LOSS_INDIVIDUAL_RHO (`forward_individual_rho`,
+        model_legacy.py:257-363); the backward of this batch uses the same variant."""
         B, r_max, mode = self._prepare(params, bn_state, batch, eps, pos_weight, loss_variant)
-        S_ptr, Soff_ptr, chunks, n_chunks = self._S_args(mode, batch)
+        S_ptr, Soff_ptr, chunks, n_chunks = self._S_args(mode, batch, loss_variant)
         _hip._check(self.L.gvae_step_forward(
             ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),
             batch.adj_dense.data_ptr(), batch.n_x.data_ptr(), batch.num_real_nodes.data_ptr(), B, r_max,
@@ -273,6 +282,9 @@ class StepEngine:
         """First half of `forward` (encoder, heads, decoder) on the current stream: all that
         `backward` needs.  `forward_match_loss` must follow for the same batch, on this or on
         another stream ordered behind this call."""
+        if loss_variant == LOSS_INDIVIDUAL_RHO:
+            raise _hip.GvaeHipError("the individual-rho loss has no split forward: its backward reads the "
+                                    "permutation, so the whole forward() has to precede it")
         B, r_max, mode = self._prepare(params, bn_state, batch, eps, pos_weight, loss_variant)
         _hip._check(self.L.gvae_step_forward_model(
             ctypes.byref(self.dims), params.data_ptr(), bn_state.data_ptr(), batch.x.data_ptr(),

@@ -28,7 +28,8 @@ import torch.nn as nn
 
 from .. import _hip
 from ..data import DenseGraphBatch, as_dense_batch
-from ..engine import LOSS_CURRENT, LOSS_DUMMY_MASKED, PARAM_NAMES, StepEngine, param_layout
+from ..engine import (LOSS_CURRENT, LOSS_DUMMY_MASKED, LOSS_INDIVIDUAL_RHO, PARAM_NAMES, StepEngine,
+                      param_layout)
 
 
 def vec_to_adj(vec: torch.Tensor, N: int, *, diag: bool = False) -> torch.Tensor:
@@ -307,18 +308,19 @@ class GraphVAE(nn.Module):
         return self.forward_with_eps(batch, eps)
 
     def forward_with_eps(self, batch: DenseGraphBatch, eps: torch.Tensor, *,
-                         legacy: bool = False) -> dict:
-        """`forward` (or, with legacy=True, `forward_old`) with caller-supplied
-        reparameterisation noise (one row per graph)."""
-        if self.rho_global is None:
+                         legacy: bool = False, individual_rho: bool = False) -> dict:
+        """`forward` (or, with legacy=True, `forward_old`; with individual_rho=True,
+        `forward_individual_rho`) with caller-supplied reparameterisation noise (one row per
+        graph)."""
+        if self.rho_global is None and not individual_rho:
             raise RuntimeError("Call `model.precompute_dataset_rho(...)` first!")
-        variant = LOSS_DUMMY_MASKED if legacy else LOSS_CURRENT
+        variant = LOSS_INDIVIDUAL_RHO if individual_rho else (LOSS_DUMMY_MASKED if legacy else LOSS_CURRENT)
         rec, kl, max_logit, logvar_max = _StepFunction.apply(self, batch, eps, variant,
                                                              *self._named_param_list())
         if self.training:
             for bn in (self.bn1, self.bn2):
                 bn.num_batches_tracked += batch.num_graphs
-        if legacy:   # reference model.py:439-440 returns no "loss" entry
+        if legacy or individual_rho:   # reference model.py:439-440 / model_legacy.py:363: no "loss" entry
             return {"rec": rec, "kl": kl, "max_logit": max_logit, "logvar_max": logvar_max}
         return {"rec": rec, "kl": kl, "loss": rec + kl, "max_logit": max_logit,
                 "logvar_max": logvar_max}
@@ -332,6 +334,17 @@ class GraphVAE(nn.Module):
         batch = as_dense_batch(data, self.max_nodes)
         eps = torch.randn(batch.num_graphs, self.z_dim, dtype=torch.float32, device=batch.device)
         return self.forward_with_eps(batch, eps, legacy=True)
+
+    def forward_individual_rho(self, data):
+        """The variant kept in the reference's graphvae/models/model_legacy.py:257-363, on this
+        model's heads (its decoder `dec` is `dec_edge`; `dec_node` takes no part and receives a
+        zero gradient): the matching runs over all max_nodes rows of the padded matrices, the
+        ground truth is permuted while the prediction stays in place, and positives are weighted
+        by each graph's own edge density.  The only variant whose loss depends on the permutation.
+        Needs no `precompute_dataset_rho`."""
+        batch = as_dense_batch(data, self.max_nodes)
+        eps = torch.randn(batch.num_graphs, self.z_dim, dtype=torch.float32, device=batch.device)
+        return self.forward_with_eps(batch, eps, individual_rho=True)
 
     @torch.no_grad()
     def sample_decode(self, z: torch.Tensor, th_edge: float = 0.5, th_node: float = 0.5) -> dict:

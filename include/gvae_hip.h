@@ -211,6 +211,12 @@ int64_t gvae_param_layout(const gvae_dims *d, int64_t *offsets, int64_t *sizes);
 #define GVAE_LOSS_DUMMY_MASKED 1  /* GraphVAE.forward_old, model.py:403-408,425-427: the node
                                      logits of padded entries are overwritten with -10 before
                                      the node loss (constant term, no gradient)               */
+#define GVAE_LOSS_INDIVIDUAL_RHO 2 /* GraphVAE.forward_individual_rho, graphvae/models/model_legacy.py:257-363, on
+                                    * the current heads (its decoder `dec` is `dec_edge`; `dec_node` takes no part):
+                                    * matching over all N rows of the padded matrices (r_max must be N), ground
+                                    * truth permuted and prediction left in place, positives weighted by each
+                                    * graph's own density; the backward reads the permutation, so it has to
+                                    * follow the matching of the same batch */
 
 /* Bytes of scratch gvae_step_forward/backward need for n_graphs graphs.  The
  * forward leaves its activations there for the backward of the same batch. */

@@ -77,9 +77,10 @@ def init_state(in_dim: int, hid: int, z: int, n: int, seed: int = 42) -> dict:
 
 
 # ----------------------------------------------------------------------------- matching
-def edge_sim_tensor(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """reference model.py:171-216"""
-    R = int((A.sum(1) > 0).sum())
+def edge_sim_tensor(A: torch.Tensor, B: torch.Tensor, all_rows: bool = False) -> torch.Tensor:
+    """reference model.py:171-216; all_rows: the older form without the cut to the real nodes
+    (model_legacy.py:141-190), otherwise the same expression"""
+    R = A.size(0) if all_rows else int((A.sum(1) > 0).sum())
     A = A[:R, :R].clone()
     B = B[:R, :R].clone()
     A.diagonal().fill_(1.0)
@@ -147,7 +148,8 @@ def vec_to_adj(vec, N):
 def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: float = 0.1,
                   mpm_iters: int = 50, tol: float = 1e-4, early_stop: bool = True,
                   no_grad_matching: bool = False, legacy_mask: bool = False,
-                  sfree_matching: bool = False, skip_matching: bool = False):
+                  sfree_matching: bool = False, skip_matching: bool = False,
+                  individual_rho: bool = False):
     """One graph through reference model.py:288-366.  `g` has x (n_x,F), adj_dense (N,N),
     num_real_nodes.  Mutates the BN running statistics in `st` when train.
     `legacy_mask` selects the older loss `forward_old` (model.py:403-408,425-427): the logits
@@ -159,7 +161,11 @@ def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: floa
     makes graphs of 64-128 nodes checkable in seconds (S would be 64 MiB - 1 GiB each).
     `skip_matching`: identity permutation (for float64 yardsticks at sizes where S does not fit:
     prediction and truth are gathered through the same permutation, model.py:325-326, so the
-    loss and its gradients do not depend on it beyond rounding)."""
+    loss and its gradients do not depend on it beyond rounding).
+    `individual_rho`: the variant `forward_individual_rho` of model_legacy.py:257-363 on the
+    current heads (its decoder `dec` is `dec_edge`; `dec_node` takes no part): matching over
+    all N rows of the padded matrices, the ground truth permuted and the prediction left in
+    place, positives weighted by the graph's own density among the first R permuted rows."""
     N = g.adj_dense.size(0)
     R = int(g.num_real_nodes)
     A_gt = g.adj_dense
@@ -189,6 +195,26 @@ def forward_graph(st: dict, g, eps: torch.Tensor, train: bool, bn_momentum: floa
     node_logits = (hn @ st["dec_node.2.weight"].t() + st["dec_node.2.bias"]).squeeze(0)
     A_hat = vec_to_adj(vec_logits, N)
     A_hat = A_hat + torch.diag(node_logits)
+
+    if individual_rho:
+        A_hat = vec_to_adj(vec_logits, N)
+        A_hat = A_hat - 10.0 * torch.eye(N)                      # model_legacy.py:291
+        with torch.no_grad():                                    # :294-310 (X is used detached)
+            S = edge_sim_tensor(A_gt, A_hat.sigmoid(), all_rows=True)
+            X, done = mpm(torch.full((N, N), 1 / N), S, mpm_iters, tol, early_stop)
+        perm = assign_perm(X)
+        A_gt_p = A_gt[perm][:, perm]                             # :313-315: prediction not permuted
+        tri = torch.triu_indices(R, R, offset=1)                 # pairs i < j < R, row-major (:324-331)
+        truth, pred = A_gt_p[tri[0], tri[1]], A_hat[tri[0], tri[1]]
+        rho = truth.sum() / (R * (R - 1) / 2 + 1e-8)             # :336-343
+        pos_weight = ((1 - rho) / (rho + 1e-8)).clamp(min=1.0, max=20)
+        rec = F.binary_cross_entropy_with_logits(pred, truth, pos_weight=pos_weight)
+        kl = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+        return SimpleNamespace(rec=rec, kl=kl, max_logit=vec_logits.detach().abs().max(),
+                               logvar_max=logvar.max().detach(), perm=perm, X=X.detach(),
+                               iters_done=done, vec_logits=vec_logits.detach(),
+                               node_logits=node_logits.detach(), P=A_hat.sigmoid().detach(),
+                               pos_weight=pos_weight.detach())
 
     def matching():
         S = edge_sim_tensor(A_gt[:R, :R], A_hat.sigmoid()[:R, :R])

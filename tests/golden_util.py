@@ -43,6 +43,18 @@ def load_g10(golden_dir):
     return G, SimpleNamespace(out=out, grads=grads, perms=perms)
 
 
+def load_g12(golden_dir):
+    """The `forward_individual_rho` fixture (model_legacy.py:257-363) with the g5 rand/id case it
+    was generated on."""
+    G = load_g5(golden_dir / "g5_forward_rand_id.npz")
+    g = np.load(golden_dir / "g12_individual_rho_rand_id.npz", allow_pickle=False)
+    out = {k[len("out/"):]: g[k] for k in g.files if k.startswith("out/")}
+    grads = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    n = len(G.graphs)
+    return G, SimpleNamespace(out=out, grads=grads, perms=[g[f"g{i}/perm"] for i in range(n)],
+                              P=[g[f"g{i}/P"] for i in range(n)], X=[g[f"g{i}/X"] for i in range(n)])
+
+
 PARAM_SHAPES = lambda F, H, Z, N: {  # noqa: E731  (reference model.py:71-89, named_parameters order)
     "conv1.bias": (H,), "conv1.lin.weight": (H, F), "bn1.weight": (H,), "bn1.bias": (H,),
     "conv2.bias": (H,), "conv2.lin.weight": (H, H), "bn2.weight": (H,), "bn2.bias": (H,),
@@ -133,7 +145,8 @@ def truth64(G, want_res: bool = False, **kw):
                                   num_real_nodes=g.num_real_nodes) for g in G.graphs]
         res = R.forward_batch(st, graphs, [e.double() for e in G.eps], train=True, **kw)
         res.loss.backward()
-        grads = {n: st[n].grad.numpy().copy() for n in R.PARAM_NAMES}
+        grads = {n: (st[n].grad.numpy().copy() if st[n].grad is not None
+                     else np.zeros(tuple(st[n].shape))) for n in R.PARAM_NAMES}
         return (grads, res) if want_res else grads
     finally:
         torch.set_default_dtype(old)

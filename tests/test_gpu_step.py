@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10,  # noqa: E402
+from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10, load_g12,  # noqa: E402
                          perm_equivalent, rel_err, truth64)
 from oracle import ref_step as R  # noqa: E402  (checker only)
 
@@ -240,6 +240,53 @@ def test_forward_old_vs_reference_golden(golden_dir, matching):
     torch.manual_seed(0)
     out2 = model.forward_old(batch)
     assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
+
+
+@pytest.mark.parametrize("matching", ["fused", "stream"])
+def test_individual_rho_vs_reference_golden(golden_dir, matching):
+    """`forward_individual_rho` (reference model_legacy.py:257-363): the ground truth is permuted and
+    the prediction is not, so a wrong permutation would change the loss.  Losses, the matching over
+    all max_nodes rows, permutations and every gradient against the imported reference's."""
+    from oracle import matching as ora
+    G, L = load_g12(golden_dir)
+    model, batch, eps = _model_and_batch(G, matching)
+    model.rho_global = None                      # not needed by this variant
+    model.train()
+    out = model.forward_with_eps(batch, eps, individual_rho=True)
+    assert "loss" not in out
+    for k in ("rec", "kl", "max_logit", "logvar_max"):
+        assert rel_err(out[k].item(), L.out[k]) < TOL, (k, out[k].item(), L.out[k])
+    B, N = batch.num_graphs, batch.max_nodes
+    assert rel_err(model._engine.debug_tensor("rec_i", B).cpu().numpy(), L.out["rec_i"]) < TOL
+    assert model.last_mpm_iterations().min() >= 1
+    X = model._engine.debug_tensor("X", B).cpu().numpy()
+    P = model._engine.debug_tensor("P", B).cpu().numpy()
+    perm = model.last_permutations().cpu().numpy()
+    A = batch.adj_dense.cpu().numpy()
+    for g, p in enumerate(L.perms):
+        off = ~np.eye(N, dtype=bool)
+        assert rel_err(P[g][off], L.P[g][off]) < TOL           # the diagonal is read as 1 by the matching
+        assert perm_equivalent(perm[g], p, X[g])
+        # the device's own (A, P) through the C oracle: X bit for bit, permutation exactly
+        Ag = A[g].copy()
+        np.fill_diagonal(Ag, 1.0)
+        Xo, _ = ora.mpm_sfree(Ag, P[g])
+        assert np.array_equal(X[g], Xo)
+        assert np.array_equal(perm[g], ora.assign_perm(Xo))
+    (out["rec"] + out["kl"]).backward()
+    got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
+    want = dict(L.grads)
+    for n in got:
+        if n.startswith("dec_node"):
+            assert not got[n].any()
+            want[n] = got[n]
+    check_grads(got, want, truth64(G, individual_rho=True), TOL)
+    torch.manual_seed(0)
+    out2 = model.forward_individual_rho(batch)
+    assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
+    # the identity permutation gives another loss: this variant consumes the matching
+    G5 = load_g5(golden_dir / "g5_forward_rand_id.npz")
+    assert abs(out["rec"].item() - float(G5.out["rec"])) > 0.1
 
 
 def test_autograd_path_equals_fused_step_path(golden_dir):

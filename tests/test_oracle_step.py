@@ -10,8 +10,8 @@ import torch
 
 from oracle import ref_step as R
 from oracle import matching as ora
-from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10, perm_equivalent,
-                         rel_err, truth64)
+from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10, load_g12,
+                         perm_equivalent, rel_err, truth64)
 
 CASES = ["grid_deg", "grid_id", "rand_deg", "rand_id"]
 TOL = 1e-5
@@ -90,6 +90,38 @@ def test_legacy_loss_matches_reference_forward_old(golden_dir):
     (res.rec + res.kl).backward()
     check_grads({n: st[n].grad.numpy() for n in R.PARAM_NAMES}, L.grads,
                 truth64(G, legacy_mask=True), LEGACY_GRAD_TOL)
+
+
+def test_individual_rho_matches_reference(golden_dir):
+    """`forward_individual_rho` (reference model_legacy.py:257-363): the one variant in which the
+    permutation moves the loss (only the ground truth is permuted)."""
+    G, L = load_g12(golden_dir)
+    st = R.make_trainable(G.state0)
+    res = R.forward_batch(st, G.graphs, G.eps, train=True, individual_rho=True)
+    for k in ("rec", "kl", "max_logit", "logvar_max"):
+        assert rel_err(getattr(res, k).detach().numpy(), L.out[k]) < TOL, k
+    assert rel_err(torch.stack([o.rec for o in res.per_graph]).detach().numpy(), L.out["rec_i"]) < TOL
+    N = G.graphs[0].adj_dense.shape[0]
+    for g, (o, p, Pref, Xref) in enumerate(zip(res.per_graph, L.perms, L.P, L.X)):
+        assert len(p) == N and rel_err(o.P.numpy(), Pref) < TOL
+        assert perm_equivalent(o.perm.numpy(), p, o.X.numpy())
+        # the matching over all N rows pinned on the reference's own P: C oracle == reference bits
+        A = G.graphs[g].adj_dense.numpy().copy()
+        np.fill_diagonal(A, 1.0)
+        Xo, _ = ora.mpm_sfree(A, Pref)
+        assert np.array_equal(Xo, Xref)
+        assert np.array_equal(ora.assign_perm(Xo), p)
+    # a wrong permutation would show: the identity gives another loss
+    assert abs(float(res.rec) - float(G.out["rec"])) > 0.1
+    (res.rec + res.kl).backward()
+    grads = {n: (st[n].grad.numpy() if st[n].grad is not None else np.zeros(tuple(st[n].shape), np.float32))
+             for n in R.PARAM_NAMES}
+    want = dict(L.grads)
+    for n in R.PARAM_NAMES:                       # the node head takes no part in this loss
+        if n.startswith("dec_node"):
+            assert not grads[n].any()
+            want[n] = grads[n]
+    check_grads(grads, want, truth64(G, individual_rho=True), TOL)
 
 
 @pytest.mark.parametrize("N", [64, 126, 128])

@@ -77,6 +77,12 @@ def _global_add_pool(h, batch):
     return torch.zeros(nb, h.size(1), dtype=h.dtype, device=h.device).index_add_(0, batch, h)
 
 
+def _global_mean_pool(h, batch):
+    nb = int(batch.max()) + 1 if batch.numel() else 1
+    cnt = torch.bincount(batch, minlength=nb).clamp(min=1).to(h.dtype).unsqueeze(-1)
+    return _global_add_pool(h, batch) / cnt
+
+
 class _Batch:  # never instantiated; only used in isinstance checks
     pass
 
@@ -87,7 +93,7 @@ def import_reference():
     tgd = types.ModuleType("torch_geometric.data")
     tgnn.GCNConv = _GCNConv
     tgnn.global_add_pool = _global_add_pool
-    tgnn.global_mean_pool = None
+    tgnn.global_mean_pool = _global_mean_pool
     tgd.Batch = _Batch
     sys.modules.update({"torch_geometric": tg, "torch_geometric.nn": tgnn,
                         "torch_geometric.data": tgd})
@@ -501,6 +507,55 @@ def gen_forward_old(ref, out: Path):
           f"diff {d:+.3e}) kl={res['kl'].item():.6f}")
 
 
+def gen_individual_rho(out: Path):
+    """G12: `forward_individual_rho` of the reference's graphvae/models/model_legacy.py:257-363 on
+    the rand/id graphs, initial state and noise of G5: the variant that permutes the ground truth
+    only (the prediction stays in place), weights positives by each graph's own density and runs
+    the matching over all max_nodes rows.  The legacy class has one decoder `dec` where the
+    current one has `dec_edge` (same shape) and `dec_node` (unused here); `id` features, for which
+    its mean pooling equals the current sum / R pooling."""
+    import importlib
+    legacy = importlib.import_module("graphvae.models.model_legacy")
+    kind, ftype = "rand", "id"
+    nxg, N = graphs_for_forward(kind)
+    graphs = [nx_to_graph(g, N, ftype) for g in nxg]
+    for g in graphs:
+        g.num_nodes = int(g.num_real_nodes)
+    H, Z = 16, 8
+    base = np.load(out / f"g5_forward_{kind}_{ftype}.npz")
+    torch.manual_seed(42)
+    model = legacy.GraphVAE(N, H, Z, N)
+    sd = {}
+    for k in base.files:
+        if not k.startswith("state0/"):
+            continue
+        name = k[len("state0/"):]
+        if name.startswith("dec_node") or name == "pos_weight_global":
+            continue
+        sd[name.replace("dec_edge", "dec")] = torch.from_numpy(base[k].copy())
+    model.load_state_dict(sd)
+    eps = [torch.from_numpy(base[f"g{i}/eps"].copy()) for i in range(len(graphs))]
+    for i, g in enumerate(graphs):
+        assert np.array_equal(base[f"g{i}/adj_dense"], g.adj_dense.numpy())
+    res, perms = run_reference_step(legacy, model, graphs, eps, train=True, method="forward_individual_rho")
+    (res["rec"] + res["kl"]).backward()
+    store = {"meta": np.array("model_legacy.forward_individual_rho on the inputs, initial state and noise of "
+                              "g5_forward_rand_id (dec <- dec_edge)"),
+             "inputs_sha": np.array(sha(np.concatenate([base[f"g{i}/adj_dense"].ravel()
+                                                        for i in range(len(graphs))])))}
+    for k in ("rec", "kl", "max_logit", "logvar_max", "rec_i", "kl_i"):
+        store[f"out/{k}"] = res[k].detach().numpy()
+    for i, p in enumerate(perms):
+        store[f"g{i}/perm"] = p
+        store[f"g{i}/P"] = res["P"][i]
+        store[f"g{i}/X"] = res["X"][i]
+    for n_, p in model.named_parameters():
+        store[f"grad/{n_.replace('dec.', 'dec_edge.')}"] = p.grad.numpy().copy()
+    np.savez_compressed(out / "g12_individual_rho_rand_id.npz", **store)
+    print(f"G12 forward_individual_rho rand/id: rec={res['rec'].item():.6f} kl={res['kl'].item():.6f} "
+          f"(forward: rec {float(base['out/rec']):.6f}); perms {[p.tolist() for p in perms[:2]]}")
+
+
 def gen_forward_large(ref, out: Path):
     """G11: forward + backward of the imported reference at the max_nodes of the larger BASELINE
     configurations (64, 126, 128) with the trainer's default widths (hid 128, z 64), on
@@ -650,7 +705,7 @@ def gen_sampler(ref, out: Path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(Path(__file__).resolve().parents[1] / "tests" / "golden"))
-    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler | forward_old | forward_large)")
+    ap.add_argument("--only", default=None, help="regenerate one fixture family only (sampler | forward_old | forward_large | individual_rho)")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
@@ -665,6 +720,9 @@ def main():
     if args.only == "forward_large":
         gen_forward_large(ref, out)
         return
+    if args.only == "individual_rho":
+        gen_individual_rho(out)
+        return
     gen_forward_test(ref, out)
     gen_reduction_orders(out)
     gen_lsap(out)
@@ -672,6 +730,7 @@ def main():
     gen_forward(ref, out)
     gen_forward_old(ref, out)
     gen_forward_large(ref, out)
+    gen_individual_rho(out)
     gen_matching(ref, out)
     gen_sampler(ref, out)
 
