@@ -1961,6 +1961,84 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
 }
 
 // ---------------------------------------------------------------------------
+// One MPM iteration before its normalisation, and its gradient, for the autograd of the public
+// `_mpm` (reference model.py:247-276 is differentiable; model_legacy2.py:670-684 pins finite
+// gradients w.r.t. X0).  Dense S (R,R,R,R) of one graph, any values.
+//   Y[i,a] = X[i,a]*S[i,i,a,a] + sum_{j != i} max_b S[i,j,a,b]*X[j,b]
+// The backward replays each maximum: its gradient goes to the maximising b, in equal shares when
+// several b tie (as torch's amax does).  Not on the training path (the step uses X detached).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mpm_pool_fwd_kernel(const float *__restrict__ S, int R,
+                                                           const float *__restrict__ X,
+                                                           float *__restrict__ Y) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * R) return;
+  const int i = e / R, a = e - i * R;
+  const int64_t R2 = (int64_t)R * R;
+  float acc = X[e] * S[((int64_t)i * R + i) * R2 + (int64_t)a * R + a];
+  for (int j = 0; j < R; ++j) {
+    if (j == i) continue;
+    const float *row = S + ((int64_t)i * R + j) * R2 + (int64_t)a * R;
+    float m = -INFINITY;
+    for (int b = 0; b < R; ++b) m = fmaxf(m, row[b] * X[j * R + b]);
+    acc += m;
+  }
+  Y[e] = acc;
+}
+
+// one lane per (i, j, a); gX must be zero on entry (atomic accumulation), gS (optional) receives
+// += so that the caller can sum over iterations
+__global__ __launch_bounds__(256) void mpm_pool_bwd_kernel(const float *__restrict__ S, int R,
+                                                           const float *__restrict__ X,
+                                                           const float *__restrict__ gY,
+                                                           float *__restrict__ gX,
+                                                           float *__restrict__ gS) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t R2 = (int64_t)R * R;
+  if (e >= R2 * R) return;
+  const int i = (int)(e / R2), j = (int)((e / R) % R), a = (int)(e % R);
+  const float g = gY[i * R + a];
+  if (j == i) {
+    const int64_t d = ((int64_t)i * R + i) * R2 + (int64_t)a * R + a;
+    atomicAdd(&gX[i * R + a], g * S[d]);
+    if (gS) gS[d] += g * X[i * R + a];
+    return;
+  }
+  const int64_t base = ((int64_t)i * R + j) * R2 + (int64_t)a * R;
+  float m = -INFINITY;
+  for (int b = 0; b < R; ++b) m = fmaxf(m, S[base + b] * X[j * R + b]);
+  int ties = 0;
+  for (int b = 0; b < R; ++b) ties += (S[base + b] * X[j * R + b] == m) ? 1 : 0;
+  if (ties == 0) return;                         // only NaNs in the row
+  const float share = g / (float)ties;
+  for (int b = 0; b < R; ++b)
+    if (S[base + b] * X[j * R + b] == m) {
+      atomicAdd(&gX[j * R + b], share * S[base + b]);
+      if (gS) gS[base + b] += share * X[j * R + b];
+    }
+}
+
+int gvae_mpm_pool_fwd(const float *d_S, int R, const float *d_X, float *d_Y, void *stream) {
+  GVAE_REQUIRE(d_S && d_X && d_Y && R > 0 && R <= 255, GVAE_EINVAL, "mpm_pool_fwd: bad arguments (R=%d)", R);
+  hipLaunchKernelGGL(mpm_pool_fwd_kernel, dim3((R * R + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     d_S, R, d_X, d_Y);
+  return check_launch("mpm_pool_fwd");
+}
+
+int gvae_mpm_pool_bwd(const float *d_S, int R, const float *d_X, const float *d_gY, float *d_gX,
+                      float *d_gS, void *stream) {
+  GVAE_REQUIRE(d_S && d_X && d_gY && d_gX && R > 0 && R <= 255, GVAE_EINVAL,
+               "mpm_pool_bwd: bad arguments (R=%d)", R);
+  hipStream_t s = (hipStream_t)stream;
+  GVAE_REQUIRE(hipMemsetAsync(d_gX, 0, sizeof(float) * (size_t)R * R, s) == hipSuccess, GVAE_ELAUNCH,
+               "mpm_pool_bwd: memset failed");
+  const int64_t n = (int64_t)R * R * R;
+  hipLaunchKernelGGL(mpm_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_S, R, d_X,
+                     d_gY, d_gX, d_gS);
+  return check_launch("mpm_pool_bwd");
+}
+
+// ---------------------------------------------------------------------------
 // The same matching for callers that cannot allocate device memory: the workspace of
 // gvae_mpm_stream (next-X buffer, queue words, ring slots, arrival counters) lives in a
 // file-scope device array instead of coming in as an argument.  Host code never passes the

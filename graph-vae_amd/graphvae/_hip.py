@@ -53,6 +53,8 @@ def lib() -> ctypes.CDLL:
                                       c_void_p]
         L.gvae_mpm_stream_static.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                              c_int, c_int64, c_int, c_float, c_int, c_void_p, c_void_p]
+        L.gvae_mpm_pool_fwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+        L.gvae_mpm_pool_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.gvae_set_stream_handoff_bytes.argtypes = [c_int64]
         L.gvae_mpm_stream_stats.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int, c_void_p]
         L.gvae_match_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
@@ -239,6 +241,25 @@ def match_stream(A, P, NS, R, R_host, X, iters: int = 50, tol: float = 1e-4, ear
                                    X.shape[1], X.shape[1] * X.shape[2], iters, tol, int(early_stop),
                                    done.data_ptr(), ws.data_ptr(), _stream()))
     return S, S_off, done
+
+
+def mpm_pool_fwd(S, X) -> torch.Tensor:
+    """Unnormalised update of one MPM iteration for a dense (R,R,R,R) S and an (R,R) X."""
+    _dev(S, torch.float32), _dev(X, torch.float32)
+    R = X.shape[0]
+    Y = torch.empty_like(X)
+    _check(lib().gvae_mpm_pool_fwd(S.data_ptr(), R, X.data_ptr(), Y.data_ptr(), _stream()))
+    return Y
+
+
+def mpm_pool_bwd(S, X, gY, gS=None) -> torch.Tensor:
+    """Gradient of mpm_pool_fwd w.r.t. X (returned); w.r.t. S added onto gS when given."""
+    _dev(S, torch.float32), _dev(X, torch.float32), _dev(gY, torch.float32)
+    R = X.shape[0]
+    gX = torch.empty_like(X)
+    _check(lib().gvae_mpm_pool_bwd(S.data_ptr(), R, X.data_ptr(), gY.data_ptr(), gX.data_ptr(),
+                                   gS.data_ptr() if gS is not None else None, _stream()))
+    return gX
 
 
 def mpm_fused_supported(r_max: int) -> bool:

@@ -79,6 +79,49 @@ class DenseGCNConv(nn.Module):
         return (dinv.unsqueeze(-1) * a * dinv.unsqueeze(-2)) @ self.lin(x) + self.bias
 
 
+def _mpm_run(X0, S, iters, tol, early_stop, dev):
+    """(X, iterations executed) of the streamed MPM kernel on one dense S."""
+    R = X0.shape[0]
+    X = X0.detach().to(dev, torch.float32).clone().contiguous().unsqueeze(0)
+    Sd = S.detach().to(dev, torch.float32).contiguous().view(-1)
+    Rt = torch.tensor([R], dtype=torch.int32, device=dev)
+    off = torch.zeros(1, dtype=torch.int64, device=dev)
+    done = _hip.mpm_stream(Sd, off, Rt, R, X, iters, tol, early_stop)
+    return X[0], done
+
+
+class _MpmFunction(torch.autograd.Function):
+    """Autograd of `_mpm`.  Forward: the streamed kernel.  Backward: the trajectory is recomputed
+    one iteration per launch (same kernel, hence the same bits), then walked backwards; every
+    step differentiates the normalisation and replays the maxima of the pooling
+    (gvae_mpm_pool_bwd)."""
+
+    @staticmethod
+    def forward(ctx, X0, S, iters, tol, early_stop, dev):
+        X, done = _mpm_run(X0, S, iters, tol, early_stop, dev)
+        ctx.save_for_backward(X0, S)
+        ctx.args = (int(done[0]), tol, dev)
+        return X.to(X0.device)
+
+    @staticmethod
+    def backward(ctx, gX):
+        X0, S = ctx.saved_tensors
+        done, tol, dev = ctx.args
+        Sd = S.detach().to(dev, torch.float32).contiguous()
+        traj = [X0.detach().to(dev, torch.float32).contiguous()]
+        for _ in range(done):
+            traj.append(_mpm_run(traj[-1], Sd, 1, tol, False, dev)[0])
+        g = gX.detach().to(dev, torch.float32).contiguous()
+        gS = torch.zeros_like(Sd) if ctx.needs_input_grad[1] else None
+        for t in range(done - 1, -1, -1):
+            Xt, Xn = traj[t], traj[t + 1]
+            nrm = _hip.mpm_pool_fwd(Sd, Xt).norm(p=2)
+            gY = ((g - Xn * (g * Xn).sum()) / nrm).contiguous()
+            g = _hip.mpm_pool_bwd(Sd, Xt, gY, gS)
+        return (g.to(X0.device) if ctx.needs_input_grad[0] else None,
+                gS.to(S.device) if gS is not None else None, None, None, None, None)
+
+
 class _StepFunction(torch.autograd.Function):
     """Autograd bridge: forward and backward both run inside libgvae_hip.so."""
 
@@ -279,22 +322,50 @@ class GraphVAE(nn.Module):
         S, _ = _hip.edge_sim(Ad, Bd, NS, Rt, [R])
         return S[: R ** 4].view(R, R, R, R).to(A.device)
 
-    @torch.no_grad()
     def _mpm(self, X0: torch.Tensor, S: torch.Tensor, iters: int = 50, tol: float = 1e-4,
              early_stop: bool = True) -> torch.Tensor:
         """Max-pool matching on an explicit S (any non-negative tensor), bit-identical to
-        reference model.py:247-276.  The result carries no autograd history (in `forward`
-        the reference detaches it before use, model.py:319)."""
-        dev = self._hip_device(X0, S)
+        reference model.py:247-276, and differentiable w.r.t. X0 and S like it (the reference
+        checks the gradient w.r.t. X0, model_legacy2.py:670-684; `forward` uses the result
+        detached, model.py:319)."""
         R = X0.shape[0]
         if tuple(S.shape) != (R, R, R, R):
             raise ValueError(f"S must be ({R},{R},{R},{R}), got {tuple(S.shape)}")
-        X = X0.detach().to(dev, torch.float32).clone().contiguous().unsqueeze(0)
-        Sd = S.detach().to(dev, torch.float32).contiguous().view(-1)
-        Rt = torch.tensor([R], dtype=torch.int32, device=dev)
-        off = torch.zeros(1, dtype=torch.int64, device=dev)
-        _hip.mpm_stream(Sd, off, Rt, R, X, iters, tol, early_stop)
-        return X[0].to(X0.device)
+        dev = self._hip_device(X0, S)
+        if torch.is_grad_enabled() and (X0.requires_grad or S.requires_grad):
+            return _MpmFunction.apply(X0, S, int(iters), float(tol), bool(early_stop), dev)
+        return _mpm_run(X0, S, iters, tol, early_stop, dev)[0].to(X0.device)
+
+    def _mpm_loop(self, X0: torch.Tensor, S: torch.Tensor, iters: int = 50) -> torch.Tensor:
+        """The reference's loop form (model.py:218-245): `iters` iterations over all max_nodes
+        rows without early stop.  Same kernel as `_mpm`; the two agree bit for bit here (the
+        reference's two forms agree to rounding, model_legacy2.py:649-667)."""
+        if tuple(X0.shape) != (self.max_nodes, self.max_nodes):
+            raise ValueError(f"X0 must be ({self.max_nodes},{self.max_nodes})")
+        return self._mpm(X0, S, iters=iters, early_stop=False)
+
+    @torch.no_grad()
+    def edge_sim_tensor_loop(self, A: torch.Tensor, B: torch.Tensor, degA: torch.Tensor,
+                             degB: torch.Tensor) -> torch.Tensor:
+        """The reference's loop form of the similarity tensor (model.py:152-169) over all
+        max_nodes rows, with the diagonals of A and B as given (no self-loop correction) and the
+        degrees supplied by the caller: S[i,i,a,a] = A[i,i] B[a,a] / (|degA[i] - degB[a]| + 1),
+        S[i,j,a,b] = A[i,j] A[i,i] A[j,j] B[a,b] B[a,a] B[b,b] for i != j and a != b, else 0.
+        The diagonal factors are folded into the two matrices before the tensor kernel forms the
+        products, so entries equal the loop's up to the rounding of that regrouping (equal bit
+        for bit when the diagonals are 0 or 1)."""
+        N = self.max_nodes
+        dev = self._hip_device(A, B)
+        Ad = A.detach().to(dev, torch.float32)[:N, :N]
+        Bd = B.detach().to(dev, torch.float32)[:N, :N]
+        dA, dB = Ad.diagonal().clone(), Bd.diagonal().clone()
+        node = dA.view(N, 1) * dB.view(1, N) / ((degA.to(dev, torch.float32).view(N, 1)
+                                                 - degB.to(dev, torch.float32).view(1, N)).abs() + 1.0)
+        As = (Ad * dA.view(N, 1) * dA.view(1, N)).contiguous().unsqueeze(0)
+        Bs = (Bd * dB.view(N, 1) * dB.view(1, N)).contiguous().unsqueeze(0)
+        Rt = torch.tensor([N], dtype=torch.int32, device=dev)
+        S, _ = _hip.edge_sim(As, Bs, node.contiguous().unsqueeze(0), Rt, [N])
+        return S[: N ** 4].view(N, N, N, N).to(A.device)
 
     # ------------------------------------------------------------------ forward
     def forward(self, data):

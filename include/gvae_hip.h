@@ -91,6 +91,16 @@ int gvae_mpm_stream(const float *d_S, const int64_t *d_S_off, int s_layout, cons
                     int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
 
+/* One MPM iteration before its normalisation, Y[i,a] = X[i,a]*S[i,i,a,a] + sum_{j != i} max_b
+ * S[i,j,a,b]*X[j,b], and the gradients of it w.r.t. X (d_gX, overwritten) and, when d_gS is not
+ * NULL, w.r.t. S (added onto d_gS): the pieces of the autograd of the public `_mpm`
+ * (graphvae/models/model.py:247-276 is differentiable; model_legacy2.py:670-684 checks the
+ * gradient w.r.t. X0).  A maximum's gradient goes to the maximising b, in equal shares between
+ * ties, as torch's amax does.  One graph, dense (R,R,R,R) S of any values, R <= 255. */
+int gvae_mpm_pool_fwd(const float *d_S, int R, const float *d_X, float *d_Y, void *stream);
+int gvae_mpm_pool_bwd(const float *d_S, int R, const float *d_X, const float *d_gY, float *d_gX,
+                      float *d_gS, void *stream);
+
 /* gvae_mpm_stream without the workspace argument, for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
  * No counterpart in the reference.  The workspace is a built-in device array of

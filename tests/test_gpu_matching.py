@@ -487,3 +487,59 @@ def test_match_stream_tail_handoff(hip):
         assert it[4] > 2 and it.max() > 10
     finally:
         hip.set_stream_handoff_bytes(128 << 20)
+
+
+def test_mpm_autograd_and_loop_forms(hip):
+    """`_mpm` is differentiable w.r.t. X0 and S (the reference pins finite gradients w.r.t. X0,
+    model_legacy2.py:670-684): gradients of the HIP path against autograd through the CPU
+    restatement of model.py:247-276; `_mpm_loop` and `edge_sim_tensor_loop` (model.py:152-169,
+    218-245) against their definitions."""
+    from graphvae.models import GraphVAE
+    from oracle import ref_step as R
+    N = 8
+    torch.manual_seed(1)
+    model = GraphVAE(1, 4, 2, N).to("cuda:0")
+    S = torch.rand(N, N, N, N)
+    X0 = torch.rand(N, N)
+    for iters, es in ((10, False), (50, True)):
+        Sg, Xg = S.clone().requires_grad_(True), X0.clone().requires_grad_(True)
+        w = torch.rand(N, N)
+        out = model._mpm(Xg, Sg, iters=iters, early_stop=es)
+        (out * w).sum().backward()
+        Sc, Xc = S.clone().requires_grad_(True), X0.clone().requires_grad_(True)
+        ref, done = R.mpm(Xc, Sc, iters, 1e-4, es)
+        (ref * w).sum().backward()
+        assert torch.allclose(out.detach().cpu(), ref.detach(), atol=2e-6)
+        assert torch.isfinite(Xg.grad).all() and torch.isfinite(Sg.grad).all()
+        for got, want in ((Xg.grad, Xc.grad), (Sg.grad, Sc.grad)):
+            scale = want.abs().max().item()
+            assert (got.cpu() - want).abs().max().item() <= 1e-4 * scale, (iters, es)
+    # without requires_grad: no history, same values
+    plain = model._mpm(X0, S, iters=10, early_stop=False)
+    assert not plain.requires_grad
+    assert torch.equal(model._mpm_loop(X0, S, iters=10), plain)
+    # the loop form of the similarity tensor, with arbitrary diagonals and caller-given degrees
+    rng = np.random.default_rng(3)
+    A = rng.random((N, N)).astype(np.float32)
+    B = rng.random((N, N)).astype(np.float32)
+    dA, dB = A.sum(1), B.sum(1)
+    want = np.zeros((N, N, N, N), np.float32)
+    for i in range(N):
+        for j in range(N):
+            for a in range(N):
+                if i == j:
+                    want[i, i, a, a] = A[i, i] * B[a, a] * (1.0 / (abs(dA[i] - dB[a]) + 1.0))
+                else:
+                    for b in range(N):
+                        if a != b:
+                            want[i, j, a, b] = A[i, j] * A[i, i] * A[j, j] * B[a, b] * B[a, a] * B[b, b]
+    got = model.edge_sim_tensor_loop(torch.from_numpy(A), torch.from_numpy(B), torch.from_numpy(dA),
+                                     torch.from_numpy(dB)).numpy()
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-9)
+    A01 = (A < 0.5).astype(np.float32)
+    np.fill_diagonal(A01, 1.0)
+    B1 = B.copy()
+    np.fill_diagonal(B1, 1.0)
+    tA, tB = torch.from_numpy(A01), torch.from_numpy(B1)          # degrees summed as torch sums them
+    got = model.edge_sim_tensor_loop(tA, tB, tA.sum(1), tB.sum(1))
+    assert torch.equal(got, model._edge_sim_tensor(tA, tB))
