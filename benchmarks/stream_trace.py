@@ -121,3 +121,18 @@ for gg in late:
             print(f"   {label}: push->first received {a[0]:.2f} | push->last received {a[1]:.2f} | X load {a[2]:.2f} "
                   f"| stream (mean item) {a[3]:.2f} | push->last streamed {a[4]:.2f} | ->arrived {a[5]:.2f} "
                   f"| normalise+push {a[6]:.2f} | whole iteration {a[7]:.2f} us | items {a[8]:.1f}")
+# ---- streaming rate of a work-group by graph size (first third of the launch: the queue is backed up)
+Rarr = np.array(Rh)[g]
+sel0 = T[:, 1] < end / 3
+shape = item & 0xF
+print("size class : items : mean item KiB : stream us : GB/s per work-group while streaming : ticket->received : X load us")
+for lo, hi in ((1, 16), (17, 24), (25, 32), (33, 40), (41, 48), (49, 56), (57, 64), (65, 80), (81, 128)):
+    m = sel0 & (Rarr >= lo) & (Rarr <= hi)
+    if m.sum() == 0:
+        continue
+    RS4 = (Rarr[m] + 3) // 4 * 4
+    nblk = np.where(shape[m] <= 8, shape[m], 1)
+    kib = rows[m] * Rarr[m] * Rarr[m] * RS4 * 4.0 / nblk / 1024.0
+    st = T[m, 3] - T[m, 2]
+    print(f"  {lo:3d}-{hi:3d} : {int(m.sum()):6d} : {kib.mean():9.1f} : {st.mean():7.2f} : {kib.sum() * 1024 / (st.sum() * 1e-6) / 1e9:7.2f} : "
+          f"{np.mean(T[m, 1] - T[m, 0]):6.2f} : {np.mean(T[m, 2] - T[m, 1]):6.2f}")

@@ -35,7 +35,11 @@ int launch_gemm(const GemmDesc &d, hipStream_t s);
 struct GemmGroup {
   GemmDesc d[GEMM_GROUP_MAX];
   int n = 0;
-  int z_begin[GEMM_GROUP_MAX + 1];
+  // the launch is one-dimensional: member k owns the work-groups [wg_begin[k], wg_begin[k+1]),
+  // numbered z-major over its tiles_x * tiles_y * (splits or batch) tiles; likewise the
+  // split-K reduction owns [red_begin[k], red_begin[k+1]) (empty for an unsplit member)
+  int wg_begin[GEMM_GROUP_MAX + 1];
+  int red_begin[GEMM_GROUP_MAX + 1];
   int tiles_x[GEMM_GROUP_MAX], tiles_y[GEMM_GROUP_MAX];
 };
 int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk_floats,
