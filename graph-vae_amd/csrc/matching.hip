@@ -481,9 +481,10 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // streaming phase of each link (measured: worth it below about a thousand items; every item
 // costs a ticket, a 4 KiB X load and an arrival, each a memory round trip).  The result nb satisfies
 // nb == ceil(R / ceil(R / nb)), so a consumer recovers the block width from nb alone.
-__host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low) {
+__host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low, int cap_kb) {
   const long long slab = 4LL * R * R * RS;
-  long long t = (slab + (2LL << 20) - 1) >> 21;
+  const long long cap = (long long)cap_kb << 10;
+  long long t = (slab + cap - 1) / cap;
   t = t < 1 ? 1 : t;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R * t;
   if (in_flight < low) t *= (low + in_flight - 1) / in_flight;
@@ -503,7 +504,8 @@ __host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive,
 //          the per-item costs (ticket, X reload, hand-off: about 12 ns of them serialised over
 //          the whole device) weigh more than the loss of parallelism, so items are made
 //          larger, up to about 512 KiB, as long as `high` items stay in flight.
-__host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive, int low, int high) {
+__host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive, int low, int high,
+                                                       int cap_kb) {
   const long long slab = 4LL * R * R * RS;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R;
   int code = 0;
@@ -512,7 +514,7 @@ __host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive,
     if (!code && slab * rpi <= (512LL << 10) && rpi <= R &&
         in_flight / rpi >= (slab * rpi <= (128LL << 10) ? high / 2 : high))
       code = c;
-  return code ? code : mpm_col_blocks(R, RS, alive, low);
+  return code ? code : mpm_col_blocks(R, RS, alive, low, cap_kb);
 }
 __host__ __device__ __forceinline__ int mpm_shape_blocks(int code) { return code <= 8 ? code : 1; }
 __host__ __device__ __forceinline__ int mpm_shape_rows(int code) { return code <= 8 ? 1 : 2 << (code - 9); }
@@ -535,6 +537,7 @@ struct MpmQueue {
   int two_buffers;            // one work-group per compute unit: two steps of loads in flight
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
+  int item_cap_kb;            // a row's slab above this many KiB is cut into column blocks
   // Hand-off of the latency-bound tail (gvae_match_stream only; handoff == nullptr: never).  Once
   // the slabs of all graphs still iterating add up to less than handoff_kb KiB, one pass over
   // them takes the device less time than the chain of dependent steps of one iteration (ticket,
@@ -819,7 +822,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
             __hip_atomic_fetch_add(Q_ALIVE_KB(q), -mpm_slab_kb(R, RS), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
           if (cont) {
-            const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high);
+            const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high, q.item_cap_kb);
             s_nb = shape_next;
             s_base = __hip_atomic_fetch_add(Q_TAIL(q), mpm_shape_items(R, shape_next),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
     if (R <= 0 || R > r_max) { shape = 0; return 0; }
     if (first_stop && ((first_stop[g] & 1) != 0 || iters <= 1)) { shape = 0; return 0; }
-    shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high);
+    shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high, q.item_cap_kb);
     return mpm_shape_items(R, shape);
   };
   __shared__ int s_kb;
@@ -1899,19 +1902,25 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess &&
                    hipMemsetAsync(q.slots, 0, 8 * (size_t)n_items, s) == hipSuccess,
                GVAE_ELAUNCH, "mpm_stream: memset failed");
-  // 1024 threads per item from 48 nodes on (slabs of 0.4 MiB and more): measured 7.07 against
-  // 6.76 TB/s at 64 nodes; below that the per-item phases dominate and 256 threads win.
-  // (Running a ragged batch as two launches, small graphs with 256 threads and a small LDS
-  // footprint, then the large ones, was measured too: 4.84 against 4.56 ms on ENZYMES-shaped
-  // batches, whose time is set by the chains of the few graphs that need all their iterations.)
-  int nt = r_max >= 48 ? 1024 : 256;
-  // measured on 256 graphs of 32 nodes with early stop: 2.77 ms at (1024, 4096) against 2.84 at
-  // (256, 2048); grouping rows at all: 16-node graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512
-  // With 1024-thread work-groups only 256 are resident (against 1280 of 256 threads), and
-  // cutting a row finer than there are work-groups to take the pieces only adds rounds of
-  // items: ENZYMES-shaped batch (64 graphs up to 126 nodes) 4.89 ms at 1024, 4.46 ms at 256.
+  // Work-group size.  256 threads (several work-groups per CU, whose per-item phases overlap)
+  // stream faster than 1024 at every size whose rows are not a multiple of 128 bytes -- steady
+  // state, TB/s at 256 / 1024 threads: 48 nodes 6.09 / 4.64, 52: 5.61 / 4.44, 57: 5.32 / 4.53,
+  // 70: 5.52 / 5.11, 82: 5.59 / 4.95, 96: 6.93 / 6.82 -- and on ragged batches; 1024 wins at
+  // exactly 64 nodes (6.97 against 6.69) and is the only shape that keeps a CU busy once the
+  // LDS of an item (X and the row maxima of the largest graph) leaves room for one work-group.
+  int nt = (r_max == 64 || 2 * (lds + 1024) > 160 * 1024) ? 1024 : 256;
+  // Items in flight below which rows are cut finer, and the size above which a row's slab is cut
+  // in any case: with 256-thread work-groups an item of a large graph would otherwise run for
+  // 100-270 us (a work-group streams 5-20 GB/s) and a round of a small batch ends on a few such
+  // items.  ENZYMES-shaped batch of 64 graphs, ms per launch at (threads, low, cap KiB):
+  // (1024, 256, 2048) 3.29, (256, 1024, 2048) 3.02, (256, 1024, 1024) 2.89, (256, 1024, 512)
+  // 2.67, (256, 1024, 256) 2.66, (256, 1024, 128) 2.84.  With 1024-thread work-groups only 256
+  // are resident, and cutting finer than there are work-groups to take the pieces only adds
+  // rounds of items.  Rows are grouped (high) while many small slabs are in flight: 16-node
+  // graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512.
   q.low = nt == 1024 ? 256 : 1024;
   q.high = 4096;
+  q.item_cap_kb = nt == 1024 ? 2048 : 512;
   // measured on launches whose LDS leaves one work-group per CU (128-node graphs; ragged batches
   // up to 126): 0.877 against 0.89 of HBM peak, no change on the ragged batch -- off
   q.two_buffers = 0;
@@ -1921,6 +1930,7 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   if (const char *e = getenv("GVAE_MPM_LOW")) q.low = atoi(e);
   if (const char *e = getenv("GVAE_MPM_HIGH")) q.high = atoi(e);
   if (const char *e = getenv("GVAE_MPM_TWO")) q.two_buffers = atoi(e);
+  if (const char *e = getenv("GVAE_MPM_CAP")) q.item_cap_kb = atoi(e);
 #endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
