@@ -813,7 +813,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           __hip_atomic_fetch_add(&q.stats[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // latency-bound tail: the graph's remaining iterations go to the S-free kernel
           // (the number of live KiB was read when the item started: a heuristic input)
-          if (cont && q.handoff && R <= q.handoff_rmax && s_alive_kb < q.handoff_kb &&
+          // (a graph that has the device to itself streams its own tensor at about a quarter of
+          // the device's rate, so its iteration takes the chain latency plus 4 x slab / rate:
+          // the batch is latency-bound for THIS graph below handoff_kb + 4 x its slab)
+          if (cont && q.handoff && R <= q.handoff_rmax &&
+              (long long)s_alive_kb < (long long)q.handoff_kb + 4LL * mpm_slab_kb(R, RS) &&
               (q.sfree_ok[g] & 2)) {
             cont = 0;
             q.handoff[g] = 1;
@@ -1834,10 +1838,17 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
   return mpm_ws_carve(nullptr, n_graphs < 0 ? 0 : n_graphs, ldx < 0 ? 0 : ldx).bytes;
 }
 
-// slab bytes of live graphs below which gvae_match_stream hands the rest to the S-free kernel
-// (0: never).  128 MiB: one pass at the streaming rate of 6.7 TB/s takes 19 us, the latency of
-// one iteration's chain of dependent steps in the queue kernel.
-static int64_t g_handoff_bytes = 128LL << 20;
+// Base of the hand-off threshold of gvae_match_stream (0: never): a graph leaves for the S-free
+// kernel once the slabs of all live graphs add up to less than this plus four of its own slabs.
+// One pass over 128 MiB at the streaming rate of 6.7 TB/s takes 19 us, the latency of one
+// iteration's chain of dependent steps in the queue kernel, and the queue needs about two such
+// latencies of work in flight to keep HBM busy; a graph that has the device to itself streams
+// its own tensor at about a quarter of the device's rate (44-57 nodes: 33-58 us per iteration).
+// Measured, ms per step / kernel's share of HBM peak with a flat threshold of 64 / 128 / 256 MiB:
+// 256 dense graphs of 32 nodes 3.51 / 3.31 / 3.01 ms, 78.3 / 81.0 / 81.3 %; 64 ENZYMES-shaped
+// graphs 3.82 / 3.70 / 3.51 ms, 53.8 / 56.6 / 59.1 %; with the per-graph term on a base of
+// 128 / 192 / 256 MiB: 3.27 / 3.14 / 3.00 ms and 3.09 / 2.88 / 2.72 ms (58.9 / 59.5 / 59.1 %).
+static int64_t g_handoff_bytes = 256LL << 20;
 #ifndef GVAE_HANDOFF_MAX_NODES
 #define GVAE_HANDOFF_MAX_NODES 88
 #endif

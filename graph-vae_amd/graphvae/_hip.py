@@ -192,7 +192,7 @@ def mpm_stream(S, S_off, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,
 
 def set_stream_handoff_bytes(n: int) -> None:
     """Live similarity-tensor bytes below which the streamed matching of the step hands its
-    last unconverged graphs to the S-free kernel (0: never; default 128 MiB)."""
+    last unconverged graphs to the S-free kernel (0: never; default 256 MiB)."""
     _check(lib().gvae_set_stream_handoff_bytes(int(n)))
 
 

@@ -132,9 +132,10 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
 /* Tail hand-off of gvae_match_stream.  With early stop, the last unconverged graphs of a batch
  * iterate on a nearly empty device, where an iteration costs the latency of the queue kernel's
  * chain of dependent steps (about 19 us), not HBM time.  Once the similarity tensors of the
- * graphs still iterating add up to less than `bytes` (default 128 MiB = 19 us at the streaming
- * rate), a graph of at most 32 nodes (where an S-free iteration takes 5 us; larger graphs gain
- * nothing) with a 0/1 adjacency leaves the queue at
+ * graphs still iterating add up to less than `bytes` (default 256 MiB: two chain latencies at
+ * the streaming rate) plus four times the graph's own tensor (alone on the device a graph
+ * streams at about a quarter of the device's rate), a graph of at most 88 nodes (an S-free
+ * iteration takes 5 us at 32 nodes, 34 us at 88) with a 0/1 adjacency leaves the queue at
  * the end of its current iteration and the S-free kernel runs its remaining iterations after
  * the streaming launch: same X and iteration counts, bit for bit.  0 = never hand off.  Applies
  * to gvae_match_stream and the streamed step only (gvae_mpm_stream takes an arbitrary S, for

@@ -467,7 +467,7 @@ def test_match_stream_tail_handoff(hip):
     ws = torch.zeros(hip.lib().gvae_mpm_stream_ws_bytes(len(Rh), N), dtype=torch.uint8, device=dev)
     try:
         streamed = {}
-        for name, thr in (("off", 0), ("default", 128 << 20), ("always", 1 << 50)):
+        for name, thr in (("off", 0), ("default", 256 << 20), ("always", 1 << 50)):
             hip.set_stream_handoff_bytes(thr)
             hip.mpm_stream_stats(ws.data_ptr(), reset=True)
             X = torch.zeros_like(X_ref)
@@ -486,7 +486,7 @@ def test_match_stream_tail_handoff(hip):
         assert streamed["always"][1] <= streamed["default"][1] <= streamed["off"][1]
         assert it[4] > 2 and it.max() > 10
     finally:
-        hip.set_stream_handoff_bytes(128 << 20)
+        hip.set_stream_handoff_bytes(256 << 20)
 
 
 def test_mpm_autograd_and_loop_forms(hip):
