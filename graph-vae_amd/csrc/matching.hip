@@ -363,12 +363,20 @@ __device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab,
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
 template <int V, bool TWO = false>
 __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab, int R, int RS,
-                                                  int a0, int Aw, const float *Xs, float *T) {
+                                                  int a0, int Aw, const float *Xs, float *T,
+                                                  int wide = 0) {
   const int cols = RS / V;
   int lpr_log2 = 0;
   constexpr int kBase = V == 4 ? 3 : (V == 2 ? 4 : 5);
   while ((1 << lpr_log2) < cols && lpr_log2 < kBase) ++lpr_log2;
   while ((cols + (1 << lpr_log2) - 1) >> lpr_log2 > 4) ++lpr_log2;
+  // wide: rows of 9..19 vectors that are not a multiple of 128 bytes go to 16 lanes each, so
+  // that one load instruction of a wavefront covers whole consecutive rows (one contiguous run
+  // of memory, every cache line touched once) instead of the first 128 bytes of eight rows.
+  // Steady state, TB/s with 8 / 16 lanes per row: 40 nodes 5.66 / 6.14, 44: 5.47 / 6.21, 52:
+  // 5.41 / 6.19, 57: 5.20 / 5.90, 60: 5.56 / 6.25, 70: 5.39 / 5.97, 75: 5.25 / 5.43; from 21
+  // vectors on (82 nodes: 5.25 / 4.56) the idle lanes of the second pass cost more.
+  if (V == 4 && wide && (cols & 7) != 0 && cols > 8 && cols <= 19) lpr_log2 = 4;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
   constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
   if constexpr (V == 4) {
@@ -382,6 +390,8 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
       case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
       case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
       case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 4 * 8 + 1: return mpm_iter_body_v4<4, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 4 * 8 + 2: return mpm_iter_body_v4<4, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
       case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
       default: break;
     }
@@ -535,6 +545,7 @@ struct MpmQueue {
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
   int two_buffers;            // one work-group per compute unit: two steps of loads in flight
+  int wide_rows;              // 16 lanes per row for rows that are not a multiple of 128 bytes
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
   int item_cap_kb;            // a row's slab above this many KiB is cut into column blocks
@@ -726,7 +737,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         SSTAMP(1);
         if ((RS & 3) == 0) {
           if (q.two_buffers) mpm_iter_dispatch<4, true>(slab, R, RS, a0, Aw, Xs, T);
-          else mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T);
+          else mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T, q.wide_rows);
         }
         else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
         else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
@@ -1935,6 +1946,7 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // measured on launches whose LDS leaves one work-group per CU (128-node graphs; ragged batches
   // up to 126): 0.877 against 0.89 of HBM peak, no change on the ragged batch -- off
   q.two_buffers = 0;
+  q.wide_rows = 1;
 #ifdef GVAE_TUNE
   // tuning builds only: launch shape and item-shape thresholds from the environment
   if (const char *e = getenv("GVAE_MPM_NT")) nt = atoi(e);
@@ -1942,6 +1954,7 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   if (const char *e = getenv("GVAE_MPM_HIGH")) q.high = atoi(e);
   if (const char *e = getenv("GVAE_MPM_TWO")) q.two_buffers = atoi(e);
   if (const char *e = getenv("GVAE_MPM_CAP")) q.item_cap_kb = atoi(e);
+  if (const char *e = getenv("GVAE_MPM_WIDE")) q.wide_rows = atoi(e);
 #endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
