@@ -32,6 +32,18 @@ constexpr size_t kMaxDynLds = 160 * 1024 - 1024;
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// gvae_match_stream in two parts (matching.hip): the streamed launch with the S-free tail either
+// run at once or left to match_stream_tail, which a caller may put on another stream behind it.
+int match_stream_run(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                     int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                     const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, bool run_tail,
+                     void *stream);
+int match_stream_tail(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                      int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                      int64_t strideX, int iters, float tol, int early_stop, int32_t *d_iters_done,
+                      void *d_ws, void *stream);
+
 }  // namespace gvae
 
 #define GVAE_REQUIRE(cond, code, ...)                       \

@@ -2146,10 +2146,36 @@ int gvae_mpm_stream_stats(void *d_ws, int64_t *h_bytes, int64_t *h_graph_iterati
   return GVAE_OK;
 }
 
-int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
-                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
-                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
-                      float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+}  // extern "C"
+
+// The iterations of the graphs the streaming kernel handed over (flags in the workspace), by the
+// S-free kernel; the flags are cleared afterwards, so a second call does nothing.  May run on
+// another stream than the streaming launch once that launch has finished there (the step runs it
+// with the assignment, beside the next batch's similarity tensor).
+int gvae::match_stream_tail(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                            int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
+                            int64_t strideX, int iters, float tol, int early_stop,
+                            int32_t *d_iters_done, void *d_ws, void *stream) {
+  if (!early_stop || iters <= 1 || n_graphs <= 0) return GVAE_OK;
+  GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
+               "match_stream (tail): null pointer");
+  const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
+  const MpmWs m = mpm_ws_carve(d_ws, n_graphs, ldx);
+  const int rc = mpm_fused_launch(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_cap, d_X, ldx, strideX,
+                                  iters, tol, early_stop, d_iters_done, nullptr, 0, nullptr, stream,
+                                  "match_stream (tail)", m.handoff);
+  if (rc) return rc;
+  GVAE_REQUIRE(hipMemsetAsync(m.handoff, 0, sizeof(int32_t) * (size_t)n_graphs, (hipStream_t)stream) ==
+                   hipSuccess,
+               GVAE_ELAUNCH, "match_stream (tail): memset failed");
+  return GVAE_OK;
+}
+
+int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                     int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                     const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, bool run_tail,
+                     void *stream) {
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_S && d_S_off && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "match_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
@@ -2192,10 +2218,19 @@ int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, con
   const bool handoff = early_stop && g_handoff_bytes > 0 && r_cap > 0;
   rc = mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
                          early_stop, d_iters_done, d_ws, true, stream, true, handoff ? r_cap : 0);
-  if (rc || !handoff) return rc;
-  return mpm_fused_launch(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_cap, d_X, ldx, strideX, iters, tol,
-                          early_stop, d_iters_done, nullptr, 0, nullptr, stream, "match_stream (tail)",
-                          m.handoff);
+  if (rc || !handoff || !run_tail) return rc;
+  return match_stream_tail(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, d_X, ldx, strideX, iters, tol,
+                           early_stop, d_iters_done, d_ws, stream);
+}
+
+extern "C" {
+
+int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                      float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
+  return match_stream_run(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, d_X,
+                          ldx, strideX, iters, tol, early_stop, d_iters_done, d_ws, true, stream);
 }
 
 static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,

@@ -392,9 +392,16 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
       const int64_t NN = (int64_t)N * N;
       for (int c = 0; c < nc; ++c) {
         const int g0 = cb[c], nb = cb[c + 1] - cb[c];
-        TRY(gvae_match_stream(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
-                              r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
-                              tol, early_stop, d_iters_done + g0, w.mpm_ws, s));
+        // One chunk of graphs of at most 32 nodes: the S-free tail is left to the assignment
+        // phase, which may run on another stream beside the next batch's similarity tensor
+        // (256 dense graphs of 32 nodes: 2.89 -> 2.81 ms per step).  Larger graphs' tail kernels
+        // (1024 threads, up to 67 KiB of LDS) find no room beside the next batch's persistent
+        // kernel and would hold back the assignment until that ends (ENZYMES-shaped batches of up
+        // to 40 / 126 nodes: 0.63 -> 0.74 and 2.67 -> 3.71 ms), so they run here, at once; so
+        // does every chunk of a chunked batch (the chunks share the queue workspace).
+        TRY(match_stream_run(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
+                             r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
+                             tol, early_stop, d_iters_done + g0, w.mpm_ws, nc > 1 || r_max > 32, s));
       }
     } else if (do_assign) {
       // S-free MPM with the assignment as its epilogue
@@ -407,6 +414,9 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
     }
   }
   if (!do_assign) return 0;
+  if (matching == GVAE_MATCH_STREAM)       // (nothing left to do after a chunked matching)
+    TRY(match_stream_tail(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
+                          mpm_iters, tol, early_stop, d_iters_done, w.mpm_ws, s));
   // assignment (model.py:319-323), unless the S-free MPM above has already done it
   if (matching == GVAE_MATCH_STREAM || (matching == GVAE_MATCH_FUSED && !do_match))
     TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
