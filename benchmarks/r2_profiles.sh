@@ -1,9 +1,10 @@
 # round-2 measurement set: bench lines of every single-GPU workload, the c4 iteration sweep,
-# PMC traffic of the streaming kernel at 128 nodes (FETCH_SIZE and WRITE_SIZE in separate passes)
+# rocprofv3 kernel stats of the default line's two legs, PMC traffic of the streaming kernel
+# (FETCH_SIZE and WRITE_SIZE in separate passes)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2p
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 timeout -k 10 300 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 timeout -k 10 300 python3 bench.py --workload c1 > $O/bench_c1.json 2> $O/bench_c1.err
 timeout -k 10 300 python3 bench.py --workload c3 --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/bench_c3.err
@@ -11,7 +12,12 @@ for it in 50 100 300; do
   timeout -k 10 400 python3 bench.py --workload c4 --mpm-iters $it --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_iters$it.json 2> $O/bench_c4_iters$it.err
 done
 timeout -k 10 400 python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_c5_fetch -o f -- python3 benchmarks/matching_bench.py 128 16 50 0 1 > $O/pmc_c5_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_c5_write -o w -- python3 benchmarks/matching_bench.py 128 16 50 0 1 > $O/pmc_c5_write.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o c2 -- python3 bench.py --no-cpu-baseline --no-fused-leg > $O/prof_c2.json 2> $O/prof_c2.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2f -o c2f -- python3 bench.py --matching fused --no-cpu-baseline > $O/prof_c2f.json 2> $O/prof_c2f.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c2_$c -o p -- python3 benchmarks/matching_bench.py 32 256 50 1 1 > $O/pmc_c2_$c.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c3_$c -o p -- python3 benchmarks/matching_ragged.py > $O/pmc_c3_$c.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c5_$c -o p -- python3 benchmarks/matching_bench.py 128 16 50 0 1 > $O/pmc_c5_$c.log 2>&1
+done
 rm -f $O/*/*.db
 echo done
