@@ -237,12 +237,12 @@ int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk
 // dense adjacency already carries a unit diagonal on the R real nodes, rows in
 // [R, n_x) are isolated feature rows with only their self loop.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gcn_norm_adj_kernel(const float *__restrict__ adj,
-                                                           const int32_t *__restrict__ n_x,
-                                                           const int32_t *__restrict__ Rarr, int N,
-                                                           float *__restrict__ Ahat) {
+__device__ __forceinline__ void gcn_norm_adj_body(const float *__restrict__ adj,
+                                                  const int32_t *__restrict__ n_x,
+                                                  const int32_t *__restrict__ Rarr, int N,
+                                                  float *__restrict__ Ahat, int g) {
   __shared__ float dinv[1024];
-  const int g = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int nx = n_x[g], R = Rarr[g];
   const float *Ag = adj + (int64_t)g * N * N;
   float *Og = Ahat + (int64_t)g * N * N;
@@ -263,6 +263,13 @@ __global__ __launch_bounds__(256) void gcn_norm_adj_kernel(const float *__restri
     }
     Og[e] = dinv[i] * a * dinv[j];
   }
+}
+
+__global__ __launch_bounds__(256) void gcn_norm_adj_kernel(const float *__restrict__ adj,
+                                                           const int32_t *__restrict__ n_x,
+                                                           const int32_t *__restrict__ Rarr, int N,
+                                                           float *__restrict__ Ahat) {
+  gcn_norm_adj_body(adj, n_x, Rarr, N, Ahat, blockIdx.x);
 }
 
 int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
@@ -288,19 +295,19 @@ __device__ __forceinline__ double quad_rows_sum(double v, double (*sh)[64], int 
   return t;
 }
 
-__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
+__device__ __forceinline__ void bn_relu_fwd_body(
     const float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ run_mean,
     const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
     float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
-    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o) {
+    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o, int g, int slab) {
   __shared__ double sh[4][64];
-  const int g = blockIdx.y, tid = threadIdx.x;
-  const int cl = tid & 63, rl = tid >> 6, c = blockIdx.x * 64 + cl;
+  const int tid = threadIdx.x;
+  const int cl = tid & 63, rl = tid >> 6, c = slab * 64 + cl;
   const bool cv = c < H;
   const int nx = n_x[g];
   // which statistics this forward normalised with: the backward of the batch reads it
-  if (mode_o && g == 0 && blockIdx.x == 0 && tid == 0) mode_o[0] = train;
+  if (mode_o && g == 0 && slab == 0 && tid == 0) mode_o[0] = train;
   const float *Yg = Y + (int64_t)g * N * H;
   float *Og = out + (int64_t)g * N * H;
   const float b = cv ? bias[c] : 0.0f;
@@ -341,6 +348,16 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
     }
     Og[(int64_t)i * H + c] = o;
   }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
+    const float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ run_mean,
+    const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
+    float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
+    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o) {
+  bn_relu_fwd_body(Y, bias, gamma, beta, run_mean, run_var, n_x, N, H, train, out, mean_o, invstd_o,
+                   var_unb_o, mode_o, blockIdx.y, blockIdx.x);
 }
 
 int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
@@ -529,12 +546,12 @@ int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, in
 
 // pooled graph vector: sum over the n_x live rows divided by the real node count
 // (reference model.py:141-142,297)
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Hm,
-                                                       const int32_t *__restrict__ n_x,
-                                                       const int32_t *__restrict__ Rarr, int N, int H,
-                                                       float *__restrict__ gvec) {
+__device__ __forceinline__ void pool_fwd_body(const float *__restrict__ Hm,
+                                              const int32_t *__restrict__ n_x,
+                                              const int32_t *__restrict__ Rarr, int N, int H,
+                                              float *__restrict__ gvec, int g, int slab) {
   __shared__ float sh[4][64];
-  const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = slab * 64 + cl;
   const int nx = n_x[g];
   float s = 0.0f;
   if (c < H) for (int i = rl; i < nx; i += 4) s += Hm[((int64_t)g * N + i) * H + c];
@@ -542,6 +559,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__
   __syncthreads();
   if (rl == 0 && c < H)
     gvec[(int64_t)g * H + c] = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) / (float)Rarr[g];
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Hm,
+                                                       const int32_t *__restrict__ n_x,
+                                                       const int32_t *__restrict__ Rarr, int N, int H,
+                                                       float *__restrict__ gvec) {
+  pool_fwd_body(Hm, n_x, Rarr, N, H, gvec, blockIdx.y, blockIdx.x);
 }
 
 int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
@@ -586,6 +610,402 @@ int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, in
   hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, mu, lvraw, eps, n,
                      z);
   return check_launch("reparam_fwd");
+}
+
+// ---------------------------------------------------------------------------
+// The model half of the forward for one graph per work-group: normalised adjacency, the two
+// GCN layers (X W^T, Ahat * ., BatchNorm + ReLU), pooling, the two heads, reparameterisation and
+// the first decoder layers, as stages of ONE kernel separated by work-group barriers.  Everything
+// up to the pooled vector is local to a graph (BatchNorm runs over a graph's own rows), so the
+// chain needs no grid-wide step; the stages are the device functions of the stand-alone kernels
+// (same tiles, same summation orders), and the intermediate tensors go through the workspace in
+// global memory as before (the backward reads them), where a work-group finds its own writes
+// after a barrier.  16 launches of 4-12 us become one.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_stage(const GemmDesc &d, int z) {
+  const int ty = (d.M + GT_M - 1) / GT_M, tx = (d.N + GT_N - 1) / GT_N;
+  for (int by = 0; by < ty; ++by)
+    for (int bx = 0; bx < tx; ++bx) {
+      gemm_tile(d, bx, by, z);
+      __syncthreads();          // the tile's stores, and its LDS operands, before the next one
+    }
+}
+
+// out[n] = [relu](bias[n] + sum_k in[k] * W[n*K + k]) for one row, one lane per output
+// (`in` was written earlier in the same kernel: no __restrict__, it must be read with ordinary
+// vector loads after the barrier)
+__device__ __forceinline__ void row_linear(const float *in, const float *__restrict__ W,
+                                           const float *__restrict__ bias, float *__restrict__ out,
+                                           int Nout, int K, int relu) {
+  for (int n = threadIdx.x; n < Nout; n += blockDim.x) {
+    const float *w = W + (int64_t)n * K;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) acc = __fmaf_rn(in[k], w[k], acc);
+    acc += bias[n];
+    out[n] = relu ? fmaxf(acc, 0.0f) : acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void model_fwd_graph_kernel(ModelFwdArgs a) {
+  const int g = blockIdx.x;
+  const int N = a.N, F = a.F, H = a.H, Z = a.Z;
+  const int64_t NH = (int64_t)N * H;
+  gcn_norm_adj_body(a.adj, a.n_x, a.R, N, a.Ahat, g);
+  GemmDesc lin, agg;
+  // layer 1
+  lin.A = a.x + (int64_t)g * N * F; lin.a_rs = F; lin.a_cs = 1;
+  lin.B = a.W1; lin.b_rs = 1; lin.b_cs = F;
+  lin.C = a.H0a + g * NH; lin.c_rs = H; lin.M = N; lin.N = H; lin.K = F;
+  gemm_stage(lin, 0);
+  agg.A = a.Ahat; agg.a_rs = N; agg.a_cs = 1; agg.a_bs = (int64_t)N * N;
+  agg.B = a.H0a; agg.b_rs = H; agg.b_cs = 1; agg.b_bs = NH;
+  agg.C = a.Y1; agg.c_rs = H; agg.c_bs = NH; agg.M = N; agg.N = H; agg.K = N;
+  gemm_stage(agg, g);
+  for (int slab = 0; slab * 64 < H; ++slab) {
+    bn_relu_fwd_body(a.Y1, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.n_x, N, H, a.train, a.H1, a.mean1,
+                     a.invstd1, a.varu1, a.bn_mode, g, slab);
+    __syncthreads();
+  }
+  // layer 2
+  lin.A = a.H1 + g * NH; lin.a_rs = H; lin.B = a.W2; lin.b_cs = H; lin.C = a.H0b + g * NH; lin.K = H;
+  gemm_stage(lin, 0);
+  agg.B = a.H0b; agg.C = a.Y2;
+  gemm_stage(agg, g);
+  for (int slab = 0; slab * 64 < H; ++slab) {
+    bn_relu_fwd_body(a.Y2, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.n_x, N, H, a.train, a.H2, a.mean2,
+                     a.invstd2, a.varu2, nullptr, g, slab);
+    __syncthreads();
+  }
+  for (int slab = 0; slab * 64 < H; ++slab) {
+    pool_fwd_body(a.H2, a.n_x, a.R, N, H, a.gvec, g, slab);
+    __syncthreads();
+  }
+  // heads, reparameterisation, first decoder layers: one row per graph
+  const float *gv = a.gvec + (int64_t)g * H;
+  row_linear(gv, a.Wmu, a.bmu, a.mu + (int64_t)g * Z, Z, H, 0);
+  row_linear(gv, a.Wlv, a.blv, a.lvraw + (int64_t)g * Z, Z, H, 0);
+  __syncthreads();
+  for (int k = threadIdx.x; k < Z; k += blockDim.x) {
+    const int64_t e = (int64_t)g * Z + k;
+    const float lv = fminf(fmaxf(a.lvraw[e], -4.0f), 4.0f);
+    a.z[e] = a.mu[e] + a.eps[e] * expf(0.5f * lv);
+  }
+  __syncthreads();
+  const float *zg = a.z + (int64_t)g * Z;
+  row_linear(zg, a.Wde1, a.bde1, a.he + (int64_t)g * H, H, Z, 1);
+  row_linear(zg, a.Wdn1, a.bdn1, a.hn + (int64_t)g * H, H, Z, 1);
+}
+
+// ---------------------------------------------------------------------------
+// The same chain for graphs of at most 64 nodes and a hidden width of at most 128 (a multiple of
+// 32), with the graph's activations resident in LDS: every stage reads its operands from LDS (the
+// weights from L2) and leaves its result there for the next one; the copies in the workspace,
+// which the backward reads, are plain stores nobody waits for.  A stage then costs its arithmetic
+// and a barrier instead of a round trip through global memory (2-5 us each in the kernel above).
+//
+// The contractions run on the matrix cores, one 32x32 tile of the result per wavefront
+// (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k l>>5] and B[k l>>5][col l&31]).  Within
+// a block of 8 consecutive k the lanes of half h hold k = 4h..4h+3, read as one 16-byte vector,
+// and instruction t of the block contracts k = t and k = 4 + t: a fixed summation order like any
+// other, with vector loads for both operands.
+// ---------------------------------------------------------------------------
+struct FwdLds {
+  int as, hs;                        // row strides (floats) of Ahat and of the activation buffers
+  int o_ah, o_b0, o_b1, o_vec;       // offsets in floats; the first 2 KiB per 256 threads are doubles
+  size_t bytes;
+};
+__host__ __device__ inline FwdLds fwd_lds_layout(int NP, int H, int Z) {
+  FwdLds L;
+  L.as = NP + 4;
+  L.hs = H + 4;
+  L.o_ah = (NP * 8 / 256) * 512;     // after double sh[NT/256][4][64]
+  L.o_b0 = L.o_ah + NP * L.as;
+  L.o_b1 = L.o_b0 + NP * L.hs;
+  L.o_vec = L.o_b1 + NP * L.hs;      // dinv[NP], gvec[H], mu[Z], lv[Z], z[Z]
+  L.bytes = (size_t)(L.o_vec + NP + H + 3 * Z) * sizeof(float);
+  return L;
+}
+
+#define MFMA4(a, b)                                                      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0)
+
+// C tile (rows m0.., cols n0..) = A (LDS, row stride as) * B, B(k, n) = Bl[k * bs + n] in LDS
+__device__ __forceinline__ f32x16 tile_lds_lds(const float *A, int as, int m0, const float *Bl, int bs,
+                                               int n0, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const float *ap = A + (m0 + r) * as + 4 * half;
+  const float *bp = Bl + (4 * half) * bs + n0 + r;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    const float4 av = *reinterpret_cast<const float4 *>(ap + k0);
+    float4 bv;
+    bv.x = bp[(k0 + 0) * bs]; bv.y = bp[(k0 + 1) * bs];
+    bv.z = bp[(k0 + 2) * bs]; bv.w = bp[(k0 + 3) * bs];
+    MFMA4(av, bv);
+  }
+  return acc;
+}
+
+// C tile = A (LDS) * W^T, W (n, k) row-major in global memory with row stride K (K % 8 == 0,
+// K <= 128): the lane's whole row segment is requested before the first multiply
+__device__ __forceinline__ f32x16 tile_lds_w(const float *A, int as, int m0, const float *__restrict__ W,
+                                             int n0, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const float *ap = A + (m0 + r) * as + 4 * half;
+  const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(n0 + r) * K + 4 * half);
+  float4 bv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    bv[u] = (8 * u < K) ? wp[2 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 acc = {0};
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (8 * u < K) {
+      const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * u);
+      MFMA4(av, bv[u]);
+    }
+  }
+  return acc;
+}
+
+// accumulator register q of lane l is C[(q & 3) + 8 * (q >> 2) + 4 * (l >> 5)][l & 31]
+__device__ __forceinline__ void tile_store(const f32x16 &acc, float *dst, int hs, int m0, int n0,
+                                           float *__restrict__ glob, int N, int H) {
+  const int lane = threadIdx.x & 63, col = n0 + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    dst[row * hs + col] = acc[q];
+    if (row < N) glob[(int64_t)row * H + col] = acc[q];
+  }
+}
+
+// BatchNorm + ReLU of src + bias (LDS) into dst (LDS) and out (global): the arithmetic of
+// bn_relu_fwd_body, a 64-column slab per 256 threads
+template <int NT>
+__device__ __forceinline__ void bn_relu_lds(const float *src, float *dst, int hs, int NP, int N, int H,
+                                            int nx, int train, const float *__restrict__ bias,
+                                            const float *__restrict__ gamma,
+                                            const float *__restrict__ beta,
+                                            const float *__restrict__ run_mean,
+                                            const float *__restrict__ run_var,
+                                            float *__restrict__ out, float *__restrict__ mean_o,
+                                            float *__restrict__ invstd_o, float *__restrict__ var_unb_o,
+                                            double *shd) {
+  const int tid = threadIdx.x, cl = tid & 63, rl = (tid >> 6) & 3, grp = tid >> 8;
+  double(*sh)[64] = reinterpret_cast<double(*)[64]>(shd + grp * 256);
+  for (int s0 = 0; s0 * 64 < H; s0 += NT / 256) {
+    const int c = (s0 + grp) * 64 + cl;
+    const bool cv = c < H;
+    const float b = cv ? bias[c] : 0.0f;
+    float mean, invstd;
+    if (train) {
+      double s = 0.0;
+      if (cv) for (int i = rl; i < nx; i += 4) s += (double)(src[i * hs + c] + b);
+      s = quad_rows_sum(s, sh, rl, cl);
+      const double mean_d = s / (double)nx;
+      double q = 0.0;
+      if (cv) for (int i = rl; i < nx; i += 4) {
+        const double dlt = (double)(src[i * hs + c] + b) - mean_d;
+        q += dlt * dlt;
+      }
+      q = quad_rows_sum(q, sh, rl, cl);
+      mean = (float)mean_d;
+      invstd = (float)(1.0 / sqrt(q / (double)nx + (double)BN_EPS));
+      if (cv && rl == 0) {
+        mean_o[c] = mean;
+        invstd_o[c] = invstd;
+        var_unb_o[c] = (float)(q / (double)(nx - 1));
+      }
+    } else {
+      mean = cv ? run_mean[c] : 0.0f;
+      invstd = cv ? 1.0f / sqrtf(run_var[c] + BN_EPS) : 0.0f;
+      if (cv && rl == 0) {
+        mean_o[c] = mean;
+        invstd_o[c] = invstd;
+      }
+    }
+    if (cv) {
+      const float ga = gamma[c], be = beta[c];
+      for (int i = rl; i < NP; i += 4) {
+        float o = 0.0f;
+        if (i < nx) {
+          const float xh = ((src[i * hs + c] + b) - mean) * invstd;
+          o = fmaxf(xh * ga + be, 0.0f);
+        }
+        dst[i * hs + c] = o;
+        if (i < N) out[(int64_t)i * H + c] = o;
+      }
+    }
+  }
+}
+
+// out[n] = [relu](bias[n] + sum_k in[k] * W[n*K + k]), in[] in LDS, K % 4 == 0, for the rows
+// n = first, first + step, ... < Nout
+__device__ __forceinline__ float row_dot4(const float *in, const float *__restrict__ w, int K) {
+  float acc = 0.0f;
+  for (int k = 0; k < K; k += 4) {
+    const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+    const float4 xv = *reinterpret_cast<const float4 *>(in + k);
+    acc = __fmaf_rn(xv.x, wv.x, acc);
+    acc = __fmaf_rn(xv.y, wv.y, acc);
+    acc = __fmaf_rn(xv.z, wv.z, acc);
+    acc = __fmaf_rn(xv.w, wv.w, acc);
+  }
+  return acc;
+}
+
+template <int NP>
+__global__ __launch_bounds__(NP * 8) void model_fwd_lds_kernel(ModelFwdArgs a) {
+  constexpr int NT = NP * 8, NW = NT / 64;
+  extern __shared__ __align__(16) float lds[];
+  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const int N = a.N, F = a.F, H = a.H, Z = a.Z;
+  const FwdLds L = fwd_lds_layout(NP, H, Z);
+  const int AS = L.as, HS = L.hs;
+  double *shd = reinterpret_cast<double *>(lds);
+  float *Ah = lds + L.o_ah, *b0 = lds + L.o_b0, *b1 = lds + L.o_b1;
+  float *dinv = lds + L.o_vec, *gv = dinv + NP, *mu_s = gv + H, *lv_s = mu_s + Z, *z_s = lv_s + Z;
+  const int nx = a.n_x[g], R = a.R[g];
+  const int64_t NH = (int64_t)N * H;
+  if (g == 0 && tid == 0) a.bn_mode[0] = a.train;   // which statistics: the backward reads it
+
+  // degrees: 8 lanes per row count the row's neighbours (exact in fp32 in any order)
+  {
+    const int i = tid >> 3, sub = tid & 7;
+    const float *Ag = a.adj + (int64_t)g * N * N;
+    float cnt = 0.0f;
+    if (i < R)
+      for (int j = sub; j < R; j += 8)
+        if (j != i) cnt += (Ag[(int64_t)i * N + j] != 0.0f) ? 1.0f : 0.0f;
+    cnt += __shfl_xor(cnt, 1, 64);
+    cnt += __shfl_xor(cnt, 2, 64);
+    cnt += __shfl_xor(cnt, 4, 64);
+    if (sub == 0) dinv[i] = (i < nx) ? 1.0f / sqrtf(1.0f + cnt) : 0.0f;
+  }
+  // X W1^T (K = F, a handful: plain fma chains), rows >= N of the buffer zero
+  {
+    const float *xg = a.x + (int64_t)g * N * F;
+    for (int e = tid; e < NP * H; e += NT) {
+      const int i = e / H, c = e - i * H;
+      float acc = 0.0f;
+      if (i < N) {
+        for (int f = 0; f < F; ++f) acc = __fmaf_rn(xg[i * F + f], a.W1[c * F + f], acc);
+        a.H0a[g * NH + e] = acc;
+      }
+      b0[i * HS + c] = acc;
+    }
+  }
+  __syncthreads();
+  {
+    const float *Ag = a.adj + (int64_t)g * N * N;
+    float *Og = a.Ahat + (int64_t)g * N * N;
+    for (int e = tid; e < NP * NP; e += NT) {
+      const int i = e / NP, j = e - i * NP;
+      float v = 0.0f;
+      if (i < nx && j < nx) {
+        if (i == j) v = 1.0f;
+        else if (i < R && j < R) v = (Ag[(int64_t)i * N + j] != 0.0f) ? 1.0f : 0.0f;
+      }
+      v = dinv[i] * v * dinv[j];
+      Ah[i * AS + j] = v;
+      if (i < N && j < N) Og[(int64_t)i * N + j] = v;
+    }
+  }
+  __syncthreads();
+  const int tn = H / 32, tiles = (NP / 32) * tn;
+  // layer 1: Y1 = Ahat * H0a -> b1;  H1 = relu(bn(Y1 + bias)) -> b0
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    tile_store(tile_lds_lds(Ah, AS, m0, b0, HS, n0, NP), b1, HS, m0, n0, a.Y1 + g * NH, N, H);
+  }
+  __syncthreads();
+  bn_relu_lds<NT>(b1, b0, HS, NP, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
+                  a.mean1 + (int64_t)g * H, a.invstd1 + (int64_t)g * H, a.varu1 + (int64_t)g * H, shd);
+  __syncthreads();
+  // layer 2: H0b = H1 * W2^T -> b1;  Y2 = Ahat * H0b -> b0;  H2 -> b1
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    tile_store(tile_lds_w(b0, HS, m0, a.W2, n0, H), b1, HS, m0, n0, a.H0b + g * NH, N, H);
+  }
+  __syncthreads();
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    tile_store(tile_lds_lds(Ah, AS, m0, b1, HS, n0, NP), b0, HS, m0, n0, a.Y2 + g * NH, N, H);
+  }
+  __syncthreads();
+  bn_relu_lds<NT>(b0, b1, HS, NP, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
+                  a.mean2 + (int64_t)g * H, a.invstd2 + (int64_t)g * H, a.varu2 + (int64_t)g * H, shd);
+  __syncthreads();
+  // pooled vector: the four row lanes of pool_fwd_body, in its order
+  {
+    float *shf = reinterpret_cast<float *>(shd);          // [4][128]
+    for (int e = tid; e < 4 * H; e += NT) {
+      const int rl = e / H, c = e - rl * H;
+      float s = 0.0f;
+      for (int i = rl; i < nx; i += 4) s += b1[i * HS + c];
+      shf[rl * 128 + c] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < H; c += NT) {
+      const float v = ((shf[c] + shf[128 + c]) + (shf[256 + c] + shf[384 + c])) / (float)R;
+      gv[c] = v;
+      a.gvec[(int64_t)g * H + c] = v;
+    }
+  }
+  __syncthreads();
+  // heads
+  for (int n = tid; n < 2 * Z; n += NT) {
+    const bool lvh = n >= Z;
+    const int o = lvh ? n - Z : n;
+    const float v = row_dot4(gv, (lvh ? a.Wlv : a.Wmu) + (int64_t)o * H, H) + (lvh ? a.blv : a.bmu)[o];
+    (lvh ? lv_s : mu_s)[o] = v;
+    (lvh ? a.lvraw : a.mu)[(int64_t)g * Z + o] = v;
+  }
+  __syncthreads();
+  for (int k = tid; k < Z; k += NT) {
+    const float lv = fminf(fmaxf(lv_s[k], -4.0f), 4.0f);
+    const float zz = mu_s[k] + a.eps[(int64_t)g * Z + k] * expf(0.5f * lv);
+    z_s[k] = zz;
+    a.z[(int64_t)g * Z + k] = zz;
+  }
+  __syncthreads();
+  // first decoder layers
+  for (int n = tid; n < 2 * H; n += NT) {
+    const bool nh = n >= H;
+    const int o = nh ? n - H : n;
+    const float v = row_dot4(z_s, (nh ? a.Wdn1 : a.Wde1) + (int64_t)o * Z, Z) + (nh ? a.bdn1 : a.bde1)[o];
+    (nh ? a.hn : a.he)[(int64_t)g * H + o] = fmaxf(v, 0.0f);
+  }
+}
+
+int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
+  GVAE_REQUIRE(a.N <= 1024, GVAE_ELIMIT, "model_fwd: N=%d > 1024", a.N);
+  auto vec16 = [](const float *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // (the weight rows are read as 16-byte vectors: an odd number of pair logits can leave the
+  // parameters behind them off that alignment)
+  const bool resident = a.N <= 64 && a.H <= 128 && a.H % 32 == 0 && a.Z % 4 == 0 && a.Z <= 128 &&
+                        vec16(a.W2) && vec16(a.Wmu) && vec16(a.Wlv) && vec16(a.Wde1) && vec16(a.Wdn1);
+  if (!resident) {
+    hipLaunchKernelGGL(model_fwd_graph_kernel, dim3(B), dim3(256), 0, s, a);
+    return check_launch("model_fwd_graph");
+  }
+  const int NP = a.N <= 32 ? 32 : 64;
+  const size_t lds = fwd_lds_layout(NP, a.H, a.Z).bytes;
+  auto launch = [&](auto kernel) -> int {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "model_fwd: cannot reserve %zu bytes of LDS: %s", lds,
+                   hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(B), dim3(NP * 8), lds, s, a);
+    return check_launch("model_fwd_lds");
+  };
+  return NP == 32 ? launch(model_fwd_lds_kernel<32>) : launch(model_fwd_lds_kernel<64>);
 }
 
 // dmu = dz + ck * mu / Z ;  dlv = dz * eps * 0.5 * exp(0.5 lv) - ck * 0.5 * (1 - exp(lv)) / Z,

@@ -45,6 +45,21 @@ struct GemmGroup {
 int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk_floats,
                       hipStream_t s);
 
+// The model half of the forward (encoder, pooling, heads, reparameterisation, first decoder
+// layers) as one launch with a work-group per graph: see model_fwd_graph_kernel.
+struct ModelFwdArgs {
+  const float *x, *adj, *eps;
+  const int32_t *n_x, *R;
+  const float *W1, *b1, *g1, *be1, *rm1, *rv1, *W2, *b2, *g2, *be2, *rm2, *rv2;
+  const float *Wmu, *bmu, *Wlv, *blv, *Wde1, *bde1, *Wdn1, *bdn1;
+  float *Ahat, *H0a, *Y1, *H1, *H0b, *Y2, *H2;
+  float *mean1, *invstd1, *varu1, *mean2, *invstd2, *varu2;
+  float *gvec, *mu, *lvraw, *z, *he, *hn;
+  int32_t *bn_mode;
+  int N, F, H, Z, train;
+};
+int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s);
+
 int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
                         float *Ahat, hipStream_t s);
 // BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics

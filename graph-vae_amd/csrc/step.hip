@@ -314,36 +314,34 @@ static int forward_model(const gvae_dims *d, const float *d_params, float *d_bn_
   const Params P = bind(d, d_params);
   float *rm1 = d_bn_state, *rv1 = rm1 + H, *rm2 = rv1 + H, *rv2 = rm2 + H;
 
-  // encoder (model.py:295-297)
-  TRY(launch_gcn_norm_adj(d_adj, d_n_x, d_R, B, N, w.Ahat, s));
-  TRY(linear_fwd(d_x, F, P.p[GVAE_P_CONV1_W], nullptr, w.H0a, B * N, H, F, 0, s));
-  TRY(aggregate(w.Ahat, w.H0a, w.Y1, B, N, H, s));
-  TRY(launch_bn_relu_fwd(w.Y1, P.p[GVAE_P_CONV1_B], P.p[GVAE_P_BN1_W], P.p[GVAE_P_BN1_B], rm1, rv1,
-                         d_n_x, B, N, H, train, w.H1, w.mean1, w.invstd1, w.varu1, w.bn_mode, s));
-  TRY(linear_fwd(w.H1, H, P.p[GVAE_P_CONV2_W], nullptr, w.H0b, B * N, H, H, 0, s));
-  TRY(aggregate(w.Ahat, w.H0b, w.Y2, B, N, H, s));
-  TRY(launch_bn_relu_fwd(w.Y2, P.p[GVAE_P_CONV2_B], P.p[GVAE_P_BN2_W], P.p[GVAE_P_BN2_B], rm2, rv2,
-                         d_n_x, B, N, H, train, w.H2, w.mean2, w.invstd2, w.varu2, nullptr, s));
+  // encoder, pooling, heads, reparameterisation, first decoder layers (model.py:295-302): one
+  // launch, a work-group per graph
+  {
+    ModelFwdArgs a;
+    a.x = d_x; a.adj = d_adj; a.eps = d_eps; a.n_x = d_n_x; a.R = d_R;
+    a.W1 = P.p[GVAE_P_CONV1_W]; a.b1 = P.p[GVAE_P_CONV1_B]; a.g1 = P.p[GVAE_P_BN1_W];
+    a.be1 = P.p[GVAE_P_BN1_B]; a.rm1 = rm1; a.rv1 = rv1;
+    a.W2 = P.p[GVAE_P_CONV2_W]; a.b2 = P.p[GVAE_P_CONV2_B]; a.g2 = P.p[GVAE_P_BN2_W];
+    a.be2 = P.p[GVAE_P_BN2_B]; a.rm2 = rm2; a.rv2 = rv2;
+    a.Wmu = P.p[GVAE_P_MU_W]; a.bmu = P.p[GVAE_P_MU_B]; a.Wlv = P.p[GVAE_P_LV_W]; a.blv = P.p[GVAE_P_LV_B];
+    a.Wde1 = P.p[GVAE_P_DE1_W]; a.bde1 = P.p[GVAE_P_DE1_B]; a.Wdn1 = P.p[GVAE_P_DN1_W];
+    a.bdn1 = P.p[GVAE_P_DN1_B];
+    a.Ahat = w.Ahat; a.H0a = w.H0a; a.Y1 = w.Y1; a.H1 = w.H1; a.H0b = w.H0b; a.Y2 = w.Y2; a.H2 = w.H2;
+    a.mean1 = w.mean1; a.invstd1 = w.invstd1; a.varu1 = w.varu1;
+    a.mean2 = w.mean2; a.invstd2 = w.invstd2; a.varu2 = w.varu2;
+    a.gvec = w.gvec; a.mu = w.mu; a.lvraw = w.lvraw; a.z = w.z; a.he = w.he; a.hn = w.hn;
+    a.bn_mode = w.bn_mode;
+    a.N = N; a.F = F; a.H = H; a.Z = Z; a.train = train;
+    TRY(launch_model_fwd_graph(a, B, s));
+  }
   if (train) {
+    // (after the launch that read the old running statistics in evaluation mode; in training
+    // mode nothing of the step reads them)
     TRY(launch_bn_running_update(w.mean1, w.varu1, B, H, 0.1f, rm1, rv1, s));
     TRY(launch_bn_running_update(w.mean2, w.varu2, B, H, 0.1f, rm2, rv2, s));
   }
-  TRY(launch_pool_fwd(w.H2, d_n_x, d_R, B, N, H, w.gvec, s));
-  // heads + reparameterisation (model.py:298-299)
-  // (contractions that do not depend on each other go out as one grouped launch)
+  // second decoder layers (model.py:302-303): contractions over the whole batch
   {
-    GemmDesc heads[2] = {
-        desc_linear_fwd(w.gvec, H, P.p[GVAE_P_MU_W], P.p[GVAE_P_MU_B], w.mu, B, Z, H, 0),
-        desc_linear_fwd(w.gvec, H, P.p[GVAE_P_LV_W], P.p[GVAE_P_LV_B], w.lvraw, B, Z, H, 0)};
-    TRY(launch_gemm_group(heads, 2, w.splitk, w.splitk_floats, s));
-  }
-  TRY(launch_reparam_fwd(w.mu, w.lvraw, d_eps, B, Z, w.z, s));
-  // decoder (model.py:302-303)
-  {
-    GemmDesc l1[2] = {
-        desc_linear_fwd(w.z, Z, P.p[GVAE_P_DE1_W], P.p[GVAE_P_DE1_B], w.he, B, H, Z, 1),
-        desc_linear_fwd(w.z, Z, P.p[GVAE_P_DN1_W], P.p[GVAE_P_DN1_B], w.hn, B, H, Z, 1)};
-    TRY(launch_gemm_group(l1, 2, w.splitk, w.splitk_floats, s));
     GemmDesc l2[2] = {
         desc_linear_fwd(w.he, H, P.p[GVAE_P_DE2_W], P.p[GVAE_P_DE2_B], w.vec, B, U, H, 0),
         desc_linear_fwd(w.hn, H, P.p[GVAE_P_DN2_W], P.p[GVAE_P_DN2_B], w.node, B, N, H, 0)};
