@@ -373,17 +373,15 @@ int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, co
 // momentum updates r <- (1-m) r + m s_g in batch order.  Their closed form
 //   r_B = (1-m)^B r_0 + sum_g m (1-m)^(B-1-g) s_g
 // is evaluated here with one work-group per column (sum in double, one rounding).
-__global__ __launch_bounds__(256) void bn_running_update_kernel(const float *__restrict__ mean,
-                                                                const float *__restrict__ var_unb,
-                                                                int B, int H, float momentum,
-                                                                float *__restrict__ run_mean,
-                                                                float *__restrict__ run_var) {
+__global__ __launch_bounds__(256) void bn_running_update_kernel(BnRunningArgs a) {
   __shared__ double sh[2][4];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const double keep = 1.0 - (double)momentum;
+  const int c = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  const int B = a.B, H = a.H;
+  const float *__restrict__ mean = a.mean[l], *__restrict__ var_unb = a.var_unb[l];
+  const double keep = 1.0 - (double)a.momentum;
   double sm = 0.0, sv = 0.0;
   for (int g = tid; g < B; g += 256) {
-    const double w = (double)momentum * pow(keep, (double)(B - 1 - g));
+    const double w = (double)a.momentum * pow(keep, (double)(B - 1 - g));
     sm += w * (double)mean[(int64_t)g * H + c];
     sv += w * (double)var_unb[(int64_t)g * H + c];
   }
@@ -395,15 +393,15 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const float *__r
   __syncthreads();
   if (tid == 0) {
     const double k0 = pow(keep, (double)B);
+    float *run_mean = a.run_mean[l], *run_var = a.run_var[l];
     run_mean[c] = (float)(k0 * (double)run_mean[c] + ((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])));
     run_var[c] = (float)(k0 * (double)run_var[c] + ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])));
   }
 }
 
-int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
-                             float *run_mean, float *run_var, hipStream_t s) {
-  hipLaunchKernelGGL(bn_running_update_kernel, dim3(H), dim3(256), 0, s, mean, var_unb, B, H,
-                     momentum, run_mean, run_var);
+int launch_bn_running_update(const BnRunningArgs &a, hipStream_t s) {
+  GVAE_REQUIRE(a.layers >= 1 && a.layers <= 2, GVAE_EINVAL, "bn_running_update: %d layers", a.layers);
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(a.H, a.layers), dim3(256), 0, s, a);
   return check_launch("bn_running_update");
 }
 
@@ -987,8 +985,7 @@ int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
   auto vec16 = [](const float *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // (the weight rows are read as 16-byte vectors: an odd number of pair logits can leave the
   // parameters behind them off that alignment)
-  const bool resident = a.N <= 64 && a.H <= 128 && a.H % 32 == 0 && a.Z % 4 == 0 && a.Z <= 128 &&
-                        vec16(a.W2) && vec16(a.Wmu) && vec16(a.Wlv) && vec16(a.Wde1) && vec16(a.Wdn1);
+  const bool resident = model_chain_resident(a.N, a.H, a.Z) && vec16(a.W2) && vec16(a.Wmu) && vec16(a.Wlv) && vec16(a.Wde1) && vec16(a.Wdn1);
   if (!resident) {
     hipLaunchKernelGGL(model_fwd_graph_kernel, dim3(B), dim3(256), 0, s, a);
     return check_launch("model_fwd_graph");
@@ -1006,6 +1003,230 @@ int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
     return check_launch("model_fwd_lds");
   };
   return NP == 32 ? launch(model_fwd_lds_kernel<32>) : launch(model_fwd_lds_kernel<64>);
+}
+
+// ---------------------------------------------------------------------------
+// Backward of the same chain, from the gradients of the two hidden decoder layers down to the
+// gradient of the first layer's linear output, again with a work-group per graph and the graph's
+// tensors in LDS.  What is summed over the batch (weight and bias gradients, the BatchNorm
+// parameters' per-graph partial sums) is left to grouped contractions / column sums afterwards.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline FwdLds bwd_lds_layout(int NP, int H, int Z) {
+  FwdLds L = fwd_lds_layout(NP, H, Z);
+  L.bytes = (size_t)(L.o_vec + 4 * H + 4 * Z) * sizeof(float);   // dhe, dhn, 2 partial rows; dz parts, dmu, dlv
+  return L;
+}
+
+// C tile = A (LDS) * W, W (k, n) row-major in global memory with row stride ldw, K <= 128
+__device__ __forceinline__ f32x16 tile_lds_wn(const float *A, int as, int m0, const float *__restrict__ W,
+                                              int ldw, int n0, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+  const float *ap = A + (m0 + r) * as + 4 * half;
+  const float *bp = W + (int64_t)(4 * half) * ldw + n0 + r;
+  float4 bv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (8 * u < K) {
+      bv[u].x = bp[(int64_t)(8 * u + 0) * ldw]; bv[u].y = bp[(int64_t)(8 * u + 1) * ldw];
+      bv[u].z = bp[(int64_t)(8 * u + 2) * ldw]; bv[u].w = bp[(int64_t)(8 * u + 3) * ldw];
+    }
+  }
+  f32x16 acc = {0};
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (8 * u < K) {
+      const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * u);
+      MFMA4(av, bv[u]);
+    }
+  }
+  return acc;
+}
+
+// The arithmetic of bn_relu_bwd_kernel for one graph.  The incoming gradient is either a buffer
+// in LDS (dsrc) or the pooled vector's gradient spread over the live rows (dgv[c] * inv_r).
+template <int NT, int NP>
+__device__ __forceinline__ void bn_relu_bwd_lds(
+    const float *dsrc, const float *dgv, float inv_r, const float *__restrict__ Yg,
+    const float *__restrict__ Og, const float *__restrict__ bias, const float *__restrict__ gamma,
+    const float *__restrict__ mean, const float *__restrict__ invstd, int nx, int N, int H,
+    bool batch_stats, float *dst, int hs, float *__restrict__ dYg, float *__restrict__ dgamma_p,
+    float *__restrict__ dbeta_p, float *__restrict__ dbias_p, double *shd) {
+  constexpr int RP = NP / 4;
+  const int tid = threadIdx.x, cl = tid & 63, rl = (tid >> 6) & 3, grp = tid >> 8;
+  double(*sh)[64] = reinterpret_cast<double(*)[64]>(shd + grp * 256);
+  for (int s0 = 0; s0 * 64 < H; s0 += NT / 256) {
+    const int c = (s0 + grp) * 64 + cl;
+    const bool cv = c < H;
+    const float b = cv ? bias[c] : 0.0f;
+    const float mu = cv ? mean[c] : 0.0f;
+    const float is = cv ? invstd[c] : 0.0f;
+    float xc[RP], dp[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      const int i = rl + 4 * q;
+      xc[q] = 0.0f;
+      dp[q] = 0.0f;
+      if (cv && i < nx) {
+        const int e = i * H + c;
+        xc[q] = (Yg[e] + b) - mu;
+        const float d = dsrc ? dsrc[i * hs + c] : dgv[c] * inv_r;
+        dp[q] = Og[e] > 0.0f ? d : 0.0f;
+      }
+    }
+    double sb = 0.0, dot = 0.0;
+#pragma unroll
+    for (int q = 0; q < RP; ++q)
+      if (rl + 4 * q < nx) {
+        sb += (double)dp[q];
+        dot += (double)dp[q] * (double)xc[q];
+      }
+    sb = quad_rows_sum(sb, sh, rl, cl);
+    dot = quad_rows_sum(dot, sh, rl, cl);
+    const float ga = cv ? gamma[c] : 0.0f;
+    const float dmean = batch_stats ? (float)(sb / (double)nx) : 0.0f;
+    const float k = batch_stats ? (float)(dot * (double)is * (double)is / (double)nx) : 0.0f;
+    double sdy = 0.0;
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      const int i = rl + 4 * q;
+      float v = 0.0f;
+      if (i < nx) v = (dp[q] - dmean - xc[q] * k) * is * ga;
+      if (cv) {
+        dst[i * hs + c] = v;
+        if (dYg && i < N) dYg[(int64_t)i * H + c] = v;
+      }
+      sdy += (double)v;
+    }
+    sdy = quad_rows_sum(sdy, sh, rl, cl);
+    if (rl == 0 && cv) {
+      dgamma_p[c] = (float)(dot * (double)is);
+      dbeta_p[c] = (float)sb;
+      dbias_p[c] = (float)sdy;
+    }
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(NP * 8) void model_bwd_lds_kernel(ModelBwdArgs a) {
+  constexpr int NT = NP * 8, NW = NT / 64;
+  extern __shared__ __align__(16) float lds[];
+  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const int N = a.N, H = a.H, Z = a.Z;
+  const FwdLds L = bwd_lds_layout(NP, H, Z);
+  const int AS = L.as, HS = L.hs;
+  double *shd = reinterpret_cast<double *>(lds);
+  float *Ah = lds + L.o_ah, *b0 = lds + L.o_b0, *b1 = lds + L.o_b1;
+  float *dhe_s = lds + L.o_vec, *dhn_s = dhe_s + H, *part = dhn_s + H;   // part[2H]
+  float *zpart = part + 2 * H, *dmu_s = zpart + 2 * Z, *dlv_s = dmu_s + Z;
+  const int nx = a.n_x[g], R = a.R[g];
+  const int64_t NH = (int64_t)N * H, gH = (int64_t)g * H, gZ = (int64_t)g * Z;
+  const bool batch_stats = a.bn_mode[0] != 0;
+  {
+    const float *Ag = a.Ahat + (int64_t)g * N * N;
+    for (int e = tid; e < NP * NP; e += NT) {
+      const int i = e / NP, j = e - i * NP;
+      Ah[i * AS + j] = (i < N && j < N) ? Ag[(int64_t)i * N + j] : 0.0f;
+    }
+    for (int t = tid; t < 2 * H; t += NT) dhe_s[t] = (t < H) ? a.dhe[gH + t] : a.dhn[gH + t - H];
+  }
+  __syncthreads();
+  // dz = dhe * W_de1 + dhn * W_dn1 (two chains side by side), then the reparameterisation + KL
+  for (int t = tid; t < 2 * Z; t += NT) {
+    const bool nh = t >= Z;
+    const int k = nh ? t - Z : t;
+    const float *src = nh ? dhn_s : dhe_s;
+    const float *__restrict__ W = (nh ? a.Wdn1 : a.Wde1) + k;
+    float acc = 0.0f;
+    for (int h = 0; h < H; ++h) acc = __fmaf_rn(src[h], W[(int64_t)h * Z], acc);
+    zpart[t] = acc;
+  }
+  __syncthreads();
+  for (int k = tid; k < Z; k += NT) {
+    float ck = a.ck;
+    if (a.d_up) ck *= a.d_up[1];
+    const float dzv = zpart[Z + k] + zpart[k];
+    const float raw = a.lvraw[gZ + k];
+    const float lv = fminf(fmaxf(raw, -4.0f), 4.0f);
+    const float dm = dzv + ck * a.mu[gZ + k] / (float)Z;
+    float dl = dzv * a.eps[gZ + k] * 0.5f * expf(0.5f * lv) - ck * 0.5f * (1.0f - expf(lv)) / (float)Z;
+    dl = (raw >= -4.0f && raw <= 4.0f) ? dl : 0.0f;
+    dmu_s[k] = dm;
+    dlv_s[k] = dl;
+    a.dz[gZ + k] = dzv;
+    a.dmu[gZ + k] = dm;
+    a.dlv[gZ + k] = dl;
+  }
+  __syncthreads();
+  // dgvec = dmu * W_mu + dlv * W_lv
+  for (int t = tid; t < 2 * H; t += NT) {
+    const bool lvh = t >= H;
+    const int h = lvh ? t - H : t;
+    const float *src = lvh ? dlv_s : dmu_s;
+    const float *__restrict__ W = (lvh ? a.Wlv : a.Wmu) + h;
+    float acc = 0.0f;
+    for (int k = 0; k < Z; ++k) acc = __fmaf_rn(src[k], W[(int64_t)k * H], acc);
+    part[t] = acc;
+  }
+  __syncthreads();
+  float *dgv = dhe_s;   // (the hidden layers' gradients are used up)
+  for (int h = tid; h < H; h += NT) {
+    const float v = part[H + h] + part[h];
+    dgv[h] = v;
+    a.dgvec[gH + h] = v;
+  }
+  __syncthreads();
+  const int tn = H / 32, tiles = (NP / 32) * tn;
+  // layer 2: pooling and BatchNorm + ReLU backward -> b0; dH0 = Ahat * dY -> b1 (Ahat is symmetric)
+  bn_relu_bwd_lds<NT, NP>(nullptr, dgv, 1.0f / (float)R, a.Y2 + g * NH, a.H2 + g * NH, a.b2, a.g2,
+                          a.mean2 + gH, a.invstd2 + gH, nx, N, H, batch_stats, b0, HS, nullptr,
+                          a.dgam2 + gH, a.dbet2 + gH, a.dbias2 + gH, shd);
+  __syncthreads();
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    tile_store(tile_lds_lds(Ah, AS, m0, b0, HS, n0, NP), b1, HS, m0, n0, a.dH0_2 + g * NH, N, H);
+  }
+  __syncthreads();
+  // layer 1: dH1 = dH0 * W2 -> b0; BatchNorm + ReLU backward -> b1; dH0 = Ahat * dY
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    const f32x16 acc = tile_lds_wn(b1, HS, m0, a.W2, H, n0, H);
+    const int lane = tid & 63, col = n0 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      b0[(m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * HS + col] = acc[q];
+  }
+  __syncthreads();
+  bn_relu_bwd_lds<NT, NP>(b0, nullptr, 0.0f, a.Y1 + g * NH, a.H1 + g * NH, a.b1, a.g1, a.mean1 + gH,
+                          a.invstd1 + gH, nx, N, H, batch_stats, b1, HS, a.dY + g * NH, a.dgam1 + gH,
+                          a.dbet1 + gH, a.dbias1 + gH, shd);
+  __syncthreads();
+  for (int t = wave; t < tiles; t += NW) {
+    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    tile_store(tile_lds_lds(Ah, AS, m0, b1, HS, n0, NP), b0, HS, m0, n0, a.dH0_1 + g * NH, N, H);
+  }
+}
+
+bool model_chain_resident(int N, int H, int Z) {
+  return N <= 64 && H <= 128 && H % 32 == 0 && Z % 4 == 0 && Z <= 128;
+}
+
+int launch_model_bwd_graph(const ModelBwdArgs &a, int B, hipStream_t s) {
+  GVAE_REQUIRE(model_chain_resident(a.N, a.H, a.Z), GVAE_ELIMIT,
+               "model_bwd: sizes outside the LDS-resident kernel (N=%d H=%d Z=%d)", a.N, a.H, a.Z);
+  const int NP = a.N <= 32 ? 32 : 64;
+  const size_t lds = bwd_lds_layout(NP, a.H, a.Z).bytes;
+  auto launch = [&](auto kernel) -> int {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "model_bwd: cannot reserve %zu bytes of LDS: %s", lds,
+                   hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(B), dim3(NP * 8), lds, s, a);
+    return check_launch("model_bwd_lds");
+  };
+  return NP == 32 ? launch(model_bwd_lds_kernel<32>) : launch(model_bwd_lds_kernel<64>);
 }
 
 // dmu = dz + ck * mu / Z ;  dlv = dz * eps * 0.5 * exp(0.5 lv) - ck * 0.5 * (1 - exp(lv)) / Z,

@@ -31,7 +31,7 @@ int launch_gemm(const GemmDesc &d, hipStream_t s);
 // Up to GEMM_GROUP_MAX GEMMs that do not depend on each other, in one launch (plus one
 // split-K reduction launch if any member is split).  launch_gemm_group hands each split
 // member its own part of the workspace (`splitk_floats` floats at `splitk_base`).
-#define GEMM_GROUP_MAX 4
+#define GEMM_GROUP_MAX 6
 struct GemmGroup {
   GemmDesc d[GEMM_GROUP_MAX];
   int n = 0;
@@ -60,6 +60,25 @@ struct ModelFwdArgs {
 };
 int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s);
 
+// Sizes the LDS-resident kernels of the model chain (forward and backward) take.
+bool model_chain_resident(int N, int H, int Z);
+// Backward of the model chain for one graph per work-group (model_bwd_lds_kernel): from the
+// gradients of the decoder's hidden layers (already masked by their ReLUs) to the gradients of
+// the two GCN layers' linear outputs, with the BatchNorm parameters' per-graph partial sums.
+struct ModelBwdArgs {
+  const float *dhe, *dhn;
+  const float *Wde1, *Wdn1, *Wmu, *Wlv, *W2;
+  const float *mu, *lvraw, *eps, *d_up;
+  const float *Ahat, *Y1, *H1, *Y2, *H2;
+  const float *b1, *g1, *mean1, *invstd1, *b2, *g2, *mean2, *invstd2;
+  const int32_t *n_x, *R, *bn_mode;
+  float *dz, *dmu, *dlv, *dgvec, *dY, *dH0_1, *dH0_2;
+  float *dgam1, *dbet1, *dbias1, *dgam2, *dbet2, *dbias2;
+  float ck;   // KL coefficient / number of graphs
+  int N, H, Z;
+};
+int launch_model_bwd_graph(const ModelBwdArgs &a, int B, hipStream_t s);
+
 int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
                         float *Ahat, hipStream_t s);
 // BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics
@@ -69,8 +88,14 @@ int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, co
                        const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
                        int H, int train, float *out, float *mean, float *invstd, float *var_unb,
                        int32_t *mode_out, hipStream_t s);
-int launch_bn_running_update(const float *mean, const float *var_unb, int B, int H, float momentum,
-                             float *run_mean, float *run_var, hipStream_t s);
+// running statistics of up to two BatchNorm layers after a training forward, in one launch
+struct BnRunningArgs {
+  const float *mean[2], *var_unb[2];
+  float *run_mean[2], *run_var[2];
+  int layers, B, H;
+  float momentum;
+};
+int launch_bn_running_update(const BnRunningArgs &a, hipStream_t s);
 // dY (B,N,H) from dOut; per-graph partial sums dgamma_p, dbeta_p, dbias_p (B,H).  mode (device):
 // non-zero if the forward used batch statistics, zero if it used the running ones.
 int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
@@ -81,7 +106,7 @@ int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, con
 int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, int accumulate,
                   hipStream_t s);
 // out[k][c] = sum_r M[k][r*ld[k] + c] for up to COLSUM_GROUP_MAX matrices in one launch
-#define COLSUM_GROUP_MAX 4
+#define COLSUM_GROUP_MAX 12
 struct ColsumGroup {
   const float *M[COLSUM_GROUP_MAX];
   float *out[COLSUM_GROUP_MAX];

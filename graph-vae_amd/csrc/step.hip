@@ -37,6 +37,8 @@ struct Workspace {
   // backward
   float *dvec, *dnode, *dhe, *dhn, *dz, *dmu, *dlv, *dgvec, *dAct, *dY, *dH0;
   float *dgam_p, *dbet_p, *dbias_p;
+  // the per-graph backward keeps both layers' results until the batch-wide sums that follow it
+  float *dH0_2, *dgam_p2, *dbet_p2, *dbias_p2;
   float *splitk;
   int64_t splitk_floats;
   int32_t *status;
@@ -77,6 +79,7 @@ static Workspace carve(const gvae_dims *d, int B, char *base) {
   w.dmu = take((int64_t)B * Z); w.dlv = take((int64_t)B * Z); w.dgvec = take(BH);
   w.dAct = take(BNH); w.dY = take(BNH); w.dH0 = take(BNH);
   w.dgam_p = take(BH); w.dbet_p = take(BH); w.dbias_p = take(BH);
+  w.dH0_2 = take(BNH); w.dgam_p2 = take(BH); w.dbet_p2 = take(BH); w.dbias_p2 = take(BH);
   // split-K partials: splits <= ceil(512 / tiles) and tiles >= M*N/4096, so
   // splits*M*N <= 512*4096 + M*N for every GEMM that is split
   int64_t mn = U * H;
@@ -335,10 +338,11 @@ static int forward_model(const gvae_dims *d, const float *d_params, float *d_bn_
     TRY(launch_model_fwd_graph(a, B, s));
   }
   if (train) {
-    // (after the launch that read the old running statistics in evaluation mode; in training
-    // mode nothing of the step reads them)
-    TRY(launch_bn_running_update(w.mean1, w.varu1, B, H, 0.1f, rm1, rv1, s));
-    TRY(launch_bn_running_update(w.mean2, w.varu2, B, H, 0.1f, rm2, rv2, s));
+    BnRunningArgs r;
+    r.mean[0] = w.mean1; r.var_unb[0] = w.varu1; r.run_mean[0] = rm1; r.run_var[0] = rv1;
+    r.mean[1] = w.mean2; r.var_unb[1] = w.varu2; r.run_mean[1] = rm2; r.run_var[1] = rv2;
+    r.layers = 2; r.B = B; r.H = H; r.momentum = 0.1f;
+    TRY(launch_bn_running_update(r, s));
   }
   // second decoder layers (model.py:302-303): contractions over the whole batch
   {
@@ -544,6 +548,49 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
     l2[1].relu_mask_act = w.he;   // backward of the hidden ReLUs, in the contraction's epilogue
     l2[3].relu_mask_act = w.hn;
     TRY(launch_gemm_group(l2, 4, w.splitk, w.splitk_floats, s));
+  }
+  if (model_chain_resident(N, H, Z)) {
+    // the per-graph part of the chain in one launch, then everything that is summed over the
+    // batch: six weight gradients as one group, twelve column sums as another
+    ModelBwdArgs a;
+    a.dhe = w.dhe; a.dhn = w.dhn;
+    a.Wde1 = P.p[GVAE_P_DE1_W]; a.Wdn1 = P.p[GVAE_P_DN1_W]; a.Wmu = P.p[GVAE_P_MU_W];
+    a.Wlv = P.p[GVAE_P_LV_W]; a.W2 = P.p[GVAE_P_CONV2_W];
+    a.mu = w.mu; a.lvraw = w.lvraw; a.eps = d_eps; a.d_up = d_up;
+    a.Ahat = w.Ahat; a.Y1 = w.Y1; a.H1 = w.H1; a.Y2 = w.Y2; a.H2 = w.H2;
+    a.b1 = P.p[GVAE_P_CONV1_B]; a.g1 = P.p[GVAE_P_BN1_W]; a.mean1 = w.mean1; a.invstd1 = w.invstd1;
+    a.b2 = P.p[GVAE_P_CONV2_B]; a.g2 = P.p[GVAE_P_BN2_W]; a.mean2 = w.mean2; a.invstd2 = w.invstd2;
+    a.n_x = d_n_x; a.R = d_R; a.bn_mode = w.bn_mode;
+    a.dz = w.dz; a.dmu = w.dmu; a.dlv = w.dlv; a.dgvec = w.dgvec; a.dY = w.dY;
+    a.dH0_1 = w.dH0; a.dH0_2 = w.dH0_2;
+    a.dgam1 = w.dgam_p; a.dbet1 = w.dbet_p; a.dbias1 = w.dbias_p;
+    a.dgam2 = w.dgam_p2; a.dbet2 = w.dbet_p2; a.dbias2 = w.dbias_p2;
+    a.ck = c_kl / (float)B;
+    a.N = N; a.H = H; a.Z = Z;
+    TRY(launch_model_bwd_graph(a, B, s));
+    GemmDesc gw[6] = {
+        desc_linear_bwd_weight(w.dhe, w.z, Z, G(GVAE_P_DE1_W), B, H, Z, nullptr),
+        desc_linear_bwd_weight(w.dhn, w.z, Z, G(GVAE_P_DN1_W), B, H, Z, nullptr),
+        desc_linear_bwd_weight(w.dmu, w.gvec, H, G(GVAE_P_MU_W), B, Z, H, nullptr),
+        desc_linear_bwd_weight(w.dlv, w.gvec, H, G(GVAE_P_LV_W), B, Z, H, nullptr),
+        desc_linear_bwd_weight(w.dH0_2, w.H1, H, G(GVAE_P_CONV2_W), B * N, H, H, nullptr),
+        desc_linear_bwd_weight(w.dH0, d_x, F, G(GVAE_P_CONV1_W), B * N, H, F, nullptr)};
+    TRY(launch_gemm_group(gw, 6, w.splitk, w.splitk_floats, s));
+    ColsumGroup cs;
+    cs.add(w.dvec, B, U, U, G(GVAE_P_DE2_B));
+    cs.add(w.dnode, B, N, N, G(GVAE_P_DN2_B));
+    cs.add(w.dhe, B, H, H, G(GVAE_P_DE1_B));
+    cs.add(w.dhn, B, H, H, G(GVAE_P_DN1_B));
+    cs.add(w.dmu, B, Z, Z, G(GVAE_P_MU_B));
+    cs.add(w.dlv, B, Z, Z, G(GVAE_P_LV_B));
+    cs.add(w.dgam_p2, B, H, H, G(GVAE_P_BN2_W));
+    cs.add(w.dbet_p2, B, H, H, G(GVAE_P_BN2_B));
+    cs.add(w.dbias_p2, B, H, H, G(GVAE_P_CONV2_B));
+    cs.add(w.dgam_p, B, H, H, G(GVAE_P_BN1_W));
+    cs.add(w.dbet_p, B, H, H, G(GVAE_P_BN1_B));
+    cs.add(w.dbias_p, B, H, H, G(GVAE_P_CONV1_B));
+    TRY(launch_colsum_group(cs, s));
+    return check_launch("step_backward");
   }
   {
     ColsumGroup cs;   // the four bias gradients of the two heads
