@@ -9,7 +9,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step begins with the kernel that normalises the adjacency (the model half's first)
 starts = [i for i, r in enumerate(rows)
-          if "gcn_norm_adj" in r["Kernel_Name"] or "model_fwd_graph" in r["Kernel_Name"]]
+          if "gcn_norm_adj" in r["Kernel_Name"] or "model_fwd_" in r["Kernel_Name"]]
 i0, i1 = starts[-back - 1], starts[-back]
 t0 = int(rows[i0]["Start_Timestamp"])
 print(f"step of {i1 - i0} kernels, {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.1f} us to the next step's first kernel")

@@ -193,6 +193,15 @@ __global__ void identity_perm_kernel(int64_t *perm, int B, int N) {
   if (e < B * N) perm[e] = e % N;
 }
 
+// running sum of rec + beta * kl over the steps of an epoch (reference train_ddp.py:316-318 adds
+// loss.item() on the host, one synchronisation per step), and a copy of the step's four scalars
+__global__ void accumulate_loss_kernel(const float *__restrict__ out4, float beta,
+                                       float *__restrict__ copy, double *__restrict__ loss_sum) {
+  const int t = threadIdx.x;
+  if (copy && t < 4) copy[t] = out4[t];
+  if (t == 0) loss_sum[0] += (double)(out4[0] + beta * out4[1]);
+}
+
 // ---- optimiser -------------------------------------------------------------------
 #define NORM_BLOCKS 256
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float *__restrict__ g, int64_t n,
@@ -716,6 +725,14 @@ int gvae_sample_decode(const gvae_dims *d, const float *d_params, const float *d
   hipLaunchKernelGGL(sample_adj_kernel, dim3(n), dim3(256), 0, s, d_edge_logits, d_node_logits, N,
                      th_edge, th_node, d_adj, d_exists, d_count);
   return check_launch("sample_decode");
+}
+
+int gvae_step_accumulate_loss(const float *d_out4, float beta, float *d_out4_copy, double *d_loss_sum,
+                              void *stream) {
+  GVAE_REQUIRE(d_out4 && d_loss_sum, GVAE_EINVAL, "step_accumulate_loss: null pointer");
+  hipLaunchKernelGGL(accumulate_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out4, beta,
+                     d_out4_copy, d_loss_sum);
+  return check_launch("step_accumulate_loss");
 }
 
 int64_t gvae_adam_ws_bytes(void) { return NORM_BLOCKS * sizeof(double); }

@@ -80,13 +80,13 @@ def _check(rc: int) -> None:
 def _stream() -> int:
     """The current stream of the CURRENT device: kernel launches go to the current device, so
     every tensor handed to the library must live there (`_dev` checks it)."""
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
     if not t.is_cuda:
         raise GvaeHipError("expected a device tensor (the HIP path has no CPU fallback)")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != torch._C._cuda_getDevice():
         raise GvaeHipError(f"tensor on {t.device} but the current device is cuda:"
                            f"{torch.cuda.current_device()}: wrap the call in torch.cuda.device(...)")
     if t.dtype != dtype or not t.is_contiguous():

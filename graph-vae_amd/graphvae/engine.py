@@ -5,6 +5,7 @@ behind the C ABI of include/gvae_hip.h.  There is no CPU or eager fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from ctypes import POINTER, c_float, c_int, c_int32, c_int64, c_void_p
 
@@ -62,6 +63,7 @@ def _bind():
     L.gvae_step_read_debug.argtypes = [POINTER(Dims), c_int, c_void_p, c_int, POINTER(c_void_p),
                                        POINTER(c_int64)]
     L.gvae_adam_ws_bytes.restype = c_int64
+    L.gvae_step_accumulate_loss.argtypes = [c_void_p, c_float, c_void_p, c_void_p, c_void_p]
     L.gvae_adam_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                  c_void_p, c_void_p]
@@ -195,17 +197,20 @@ class StepEngine:
             return MATCH_FUSED if _hip.mpm_fused_supported(r_max) else MATCH_STREAM
         return _MATCH[self.matching]
 
-    def _ensure_S(self, r_host) -> None:
+    def _ensure_S(self, r_host, stream=None) -> None:
         key = tuple(r_host)
         if key == self._S_key:
             return
         begin, offs, largest = _hip.s_chunks(r_host, self.s_budget_bytes // 4)
-        if self._S is None or self._S.numel() < largest:
-            self._S = None  # release before growing
-            self._S = torch.empty(max(largest, 4), dtype=torch.float32, device=self.device)
-        # staged through pinned memory: a pageable upload would make the host wait for the
-        # device to drain on every batch with a new size pattern
-        self._S_off = torch.tensor(offs, dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
+        # allocation and upload on the stream the matching runs on: the kernels that read the
+        # offsets are ordered behind the copy only there
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            if self._S is None or self._S.numel() < largest:
+                self._S = None  # release before growing
+                self._S = torch.empty(max(largest, 4), dtype=torch.float32, device=self.device)
+            # staged through pinned memory: a pageable upload would make the host wait for the
+            # device to drain on every batch with a new size pattern
+            self._S_off = torch.tensor(offs, dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
         self._S_chunks = (c_int32 * len(begin))(*begin)
         self._S_key = key
 
@@ -243,13 +248,13 @@ class StepEngine:
         individual-rho loss (reference model_legacy.py:294-300)."""
         return (self.N,) * batch.num_graphs if loss_variant == LOSS_INDIVIDUAL_RHO else batch.r_host
 
-    def _S_args(self, mode: int, batch: DenseGraphBatch, loss_variant: int = LOSS_CURRENT):
+    def _S_args(self, mode: int, batch: DenseGraphBatch, loss_variant: int = LOSS_CURRENT, stream=None):
         if mode != MATCH_STREAM:
             return None, None, None, 0
-        self._ensure_S(self._matched_sizes(batch, loss_variant))
+        self._ensure_S(self._matched_sizes(batch, loss_variant), stream)
         # the shared buffers are used on whichever stream runs the matching: the allocator must
         # not hand their memory out again while that stream still reads it
-        cur = torch.cuda.current_stream(self.device)
+        cur = stream if stream is not None else torch.cuda.current_stream(self.device)
         self._S.record_stream(cur)
         self._S_off.record_stream(cur)
         return (self._S.data_ptr(), self._S_off.data_ptr(), self._S_chunks, len(self._S_chunks) - 1)
@@ -295,9 +300,11 @@ class StepEngine:
         self._pending = (B, r_max, mode, pos_weight, PHASE_MATCH | PHASE_ASSIGN_LOSS)
         self.last_mode = mode
 
-    def forward_match_loss(self, phases: int = PHASE_MATCH | PHASE_ASSIGN_LOSS) -> torch.Tensor:
+    def forward_match_loss(self, phases: int = PHASE_MATCH | PHASE_ASSIGN_LOSS,
+                           stream: "torch.cuda.Stream | None" = None) -> torch.Tensor:
         """Second half of `forward` (matching, assignment, losses) for the batch of the last
-        `forward_model` on this slot, enqueued on the CURRENT stream; returns the device tensor
+        `forward_model` on this slot, enqueued on `stream` (default: the current one; passing the
+        stream saves the caller a stream context per call); returns the device tensor
         [rec, kl, max_logit, logvar_max] (engine memory, valid once PHASE_ASSIGN_LOSS has run).
         The parameter gradients do not depend on the permutation (reference model.py:325-334
         gathers prediction and truth through the same permutation), so this may run concurrently
@@ -314,8 +321,8 @@ class StepEngine:
         batch, _eps, loss_variant = self._fwd_batch
         todo &= ~phases
         self._pending = (B, r_max, mode, pos_weight, todo) if todo else None
-        S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch) if phases & PHASE_MATCH
-                                             else (None, None, None, 0))
+        S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch, stream=stream)
+                                             if phases & PHASE_MATCH else (None, None, None, 0))
         if mode == MATCH_STREAM and not (phases & PHASE_MATCH):
             S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()    # validated, unused
         _hip._check(self.L.gvae_step_forward_match_loss(
@@ -323,8 +330,19 @@ class StepEngine:
             r_max, pos_weight.data_ptr(), loss_variant, mode, self.mpm_iters, self.tol,
             int(self.early_stop), S_ptr, Soff_ptr, chunks, n_chunks, self._ws.data_ptr(),
             self.out4.data_ptr(), self.perm.data_ptr(), self.iters_done.data_ptr(), int(phases),
-            _hip._stream()))
+            stream.cuda_stream if stream is not None else _hip._stream()))
         return self.out4
+
+    def accumulate_loss(self, out4: torch.Tensor, beta: float, loss_sum: torch.Tensor,
+                        copy: "torch.Tensor | None" = None, stream: "torch.cuda.Stream | None" = None) -> None:
+        """loss_sum[0] (float64) += out4[0] + beta * out4[1], and `copy` (4 floats) = out4, as one
+        launch on `stream` (default: the current one)."""
+        _hip._dev(out4, torch.float32), _hip._dev(loss_sum, torch.float64)
+        if copy is not None:
+            _hip._dev(copy, torch.float32)
+        _hip._check(self.L.gvae_step_accumulate_loss(
+            out4.data_ptr(), float(beta), copy.data_ptr() if copy is not None else None,
+            loss_sum.data_ptr(), stream.cuda_stream if stream is not None else _hip._stream()))
 
     def backward(self, params: torch.Tensor, pos_weight: torch.Tensor, grads: torch.Tensor,
                  c_rec: float = 1.0, c_kl: float = 1.0, d_up: torch.Tensor | None = None) -> None:

@@ -357,26 +357,28 @@ class TrainStep:
             self._ev_model[k].record(main)
 
             def enqueue_matching():
-                last = self._side
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(self._ev_model[k])
-                    if self._tail is None:
-                        out = eng.forward_match_loss()
-                    else:
-                        eng.forward_match_loss(PHASE_MATCH)
-                        self._ev_mpm[k].record(self._side)
-                if self._tail is not None:
-                    last = self._tail
-                    with torch.cuda.stream(self._tail):
-                        self._tail.wait_event(self._ev_mpm[k])
-                        out = eng.forward_match_loss(PHASE_ASSIGN_LOSS)
-                with torch.cuda.stream(last):
-                    out = out.clone()
-                    self.loss_sum += (out[0] + beta * out[1]).double()
-                    if self._ev_match[k] is None:
-                        self._ev_match[k] = torch.cuda.Event()
-                    self._ev_match[k].record(last)
-                out.record_stream(main)
+                # (streams are passed to the engine; a stream context costs the host more than
+                # the launches it would wrap)
+                side, tail = self._side, self._tail
+                side.wait_event(self._ev_model[k])
+                if tail is None:
+                    res, last = eng.forward_match_loss(stream=side), side
+                else:
+                    eng.forward_match_loss(PHASE_MATCH, stream=side)
+                    self._ev_mpm[k].record(side)
+                    tail.wait_event(self._ev_mpm[k])
+                    res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
+                out = torch.empty_like(res)          # allocated on the current stream, written on `last`
+                out.record_stream(last)
+                if hasattr(eng, "accumulate_loss"):
+                    eng.accumulate_loss(res, beta, self.loss_sum, copy=out, stream=last)
+                else:
+                    with torch.cuda.stream(last):
+                        out.copy_(res)
+                        self.loss_sum += (out[0] + beta * out[1]).double()
+                if self._ev_match[k] is None:
+                    self._ev_match[k] = torch.cuda.Event()
+                self._ev_match[k].record(last)
                 return out
 
             # pipelined: the main chain is enqueued first (the runtime makes the host wait once a
@@ -402,8 +404,8 @@ class TrainStep:
             # join: what follows on this stream (the caller reading the losses, the next forward
             # overwriting the workspace) is ordered behind the matching half
             main.wait_event(self._ev_match[k])
-        for bn in (model.bn1, model.bn2):
-            bn.num_batches_tracked += batch.num_graphs
+        torch._foreach_add_([model.bn1.num_batches_tracked, model.bn2.num_batches_tracked],
+                            batch.num_graphs)
         return out4
 
 

@@ -314,6 +314,13 @@ int gvae_step_backward(const gvae_dims *d, const float *d_params, const float *d
 int gvae_step_read_debug(const gvae_dims *d, int n_graphs, void *d_ws, int which, float **out_ptr,
                          int64_t *out_count);
 
+/* Epoch loss without a host synchronisation per step; replaces `sum_loss_tr += loss.item()`
+ * (graphvae/train/train_ddp.py:316-318): d_loss_sum[0] += rec + beta * kl from the four scalars a
+ * forward left in d_out4 (float arithmetic as the reference's `loss`, summed in double), and
+ * d_out4_copy (nullable, 4 floats) receives a copy of them.  One launch on `stream`. */
+int gvae_step_accumulate_loss(const float *d_out4, float beta, float *d_out4_copy, double *d_loss_sum,
+                              void *stream);
+
 /* Global-norm clipping + Adam with L2 weight decay on the flat buffers; replaces
  * clip_grad_norm_ + torch.optim.Adam.step, graphvae/train/train_ddp.py:243,292,316.
  * Gradients are first multiplied by grad_scale (1/world_size after a SUM all-reduce).
