@@ -383,6 +383,9 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
     d_R = w.r_full;
     r_max = N;
   }
+  // One chunk of graphs of at most 32 nodes: the streamed matching leaves its S-free tail to the
+  // assignment phase (both phases are told the same chunk list)
+  const bool tail_deferred = matching == GVAE_MATCH_STREAM && n_chunks <= 1 && r_max <= 32;
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
     if (do_match) {
@@ -412,7 +415,7 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
         // does every chunk of a chunked batch (the chunks share the queue workspace).
         TRY(match_stream_run(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
                              r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
-                             tol, early_stop, d_iters_done + g0, w.mpm_ws, nc > 1 || r_max > 32, s));
+                             tol, early_stop, d_iters_done + g0, w.mpm_ws, !tail_deferred, s));
       }
     } else if (do_assign) {
       // S-free MPM with the assignment as its epilogue
@@ -425,7 +428,9 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
     }
   }
   if (!do_assign) return 0;
-  if (matching == GVAE_MATCH_STREAM)       // (nothing left to do after a chunked matching)
+  // (only then: the hand-off flags sit where a launch over all B graphs puts them, and a chunked
+  // matching, whose launches are smaller, neither writes nor clears that place)
+  if (tail_deferred)
     TRY(match_stream_tail(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
                           mpm_iters, tol, early_stop, d_iters_done, w.mpm_ws, s));
   // assignment (model.py:319-323), unless the S-free MPM above has already done it

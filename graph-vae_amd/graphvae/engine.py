@@ -324,7 +324,10 @@ class StepEngine:
         S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch, stream=stream)
                                              if phases & PHASE_MATCH else (None, None, None, 0))
         if mode == MATCH_STREAM and not (phases & PHASE_MATCH):
-            S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()    # validated, unused
+            # (the buffer is validated, not used; the chunk list tells the assignment phase
+            # whether the matching left its S-free tail to it)
+            S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()
+            chunks, n_chunks = self._S_chunks, len(self._S_chunks) - 1
         _hip._check(self.L.gvae_step_forward_match_loss(
             ctypes.byref(self.dims), batch.adj_dense.data_ptr(), batch.num_real_nodes.data_ptr(), B,
             r_max, pos_weight.data_ptr(), loss_variant, mode, self.mpm_iters, self.tol,

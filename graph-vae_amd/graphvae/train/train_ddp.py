@@ -281,6 +281,7 @@ class TrainStep:
         self._tail = None       # pipelined: third stream for assignment + losses
         self._ev_model = self._ev_match = self._ev_mpm = None
         self._slot = 0
+        self.n_slots = int(os.environ.get("GVAE_PIPELINE_SLOTS", "3"))
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)
@@ -334,9 +335,9 @@ class TrainStep:
         if overlap:
             if self._side is None:
                 self._side = concurrent_stream(self.grads.device, tries=self.probe_tries)
-                self._ev_model = [torch.cuda.Event(), torch.cuda.Event()]
-                self._ev_mpm = [torch.cuda.Event(), torch.cuda.Event()]
-                self._ev_match = [None, None]
+                self._ev_model = [torch.cuda.Event() for _ in range(self.n_slots)]
+                self._ev_mpm = [torch.cuda.Event() for _ in range(self.n_slots)]
+                self._ev_match = [None] * self.n_slots
                 if self.pipeline:
                     # assignment + losses of step N (one wavefront per graph, latency-bound) run
                     # beside the similarity tensor and the MPM of step N+1
@@ -399,7 +400,7 @@ class TrainStep:
                       grad_scale=1.0 / self.world, norm_out=self.grad_norm)
         if overlap and self.pipeline:
             out4 = enqueue_matching()
-            self._slot ^= 1
+            self._slot = (self._slot + 1) % self.n_slots
         if overlap and not self.pipeline:
             # join: what follows on this stream (the caller reading the losses, the next forward
             # overwriting the workspace) is ordered behind the matching half

@@ -279,7 +279,10 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
  * Arguments as in gvae_step_forward.  `phases` selects what the call enqueues: GVAE_PHASE_MATCH
  * (similarity tensor and MPM), GVAE_PHASE_ASSIGN_LOSS (assignment, losses, diagnostics; after
  * the matching of the same batch) or both; a caller with a third stream lets the assignment
- * of one batch (one wavefront per graph, latency-bound) run beside the matching of the next. */
+ * of one batch (one wavefront per graph, latency-bound) run beside the matching of the next.
+ * Two calls for one batch must be given the same matching mode, r_max and chunk list: a streamed
+ * matching of one chunk of graphs of at most 32 nodes leaves the last iterations of its slowest
+ * graphs to the assignment phase. */
 #define GVAE_PHASE_MATCH 1
 #define GVAE_PHASE_ASSIGN_LOSS 2
 int gvae_step_forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,

@@ -367,7 +367,13 @@ def test_chunked_streamed_matching_equals_one_chunk():
         model = GraphVAE(1, 32, 16, N, matching="stream", s_budget_bytes=budget)
         model.precompute_dataset_rho([hb])
         model = model.to(DEV).train()
-        out = model.forward_with_eps(hb.to(DEV), eps.to(DEV))
+        # a workspace full of non-zero words: nothing in it may be read before it is written
+        # (recycled allocator blocks are not zero)
+        dev_batch = hb.to(DEV)
+        eng = model._engine_for(dev_batch)
+        eng._ensure(B)
+        eng._ws.fill_(0xA5)
+        out = model.forward_with_eps(dev_batch, eps.to(DEV))
         out["loss"].backward()
         n_chunks = len(model._engine._S_chunks) - 1
         grads = torch.cat([p.grad.reshape(-1) for p in model._named_param_list()])
