@@ -19,5 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c3_$c -o p -- python3 benchmarks/matching_ragged.py > $O/pmc_c3_$c.log 2>&1
   timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c5_$c -o p -- python3 benchmarks/matching_bench.py 128 16 50 0 1 > $O/pmc_c5_$c.log 2>&1
 done
+# matrix-core activity of the fused leg's model kernels (one pass of its own)
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_c2f -o p -- python3 bench.py --matching fused --steps 10 --warmup 2 --no-cpu-baseline > $O/pmc_mfma_c2f.log 2>&1
+python3 benchmarks/pmc_summary.py $O/pmc_mfma_c2f $O/pmc_mfma_c2f.csv gvae
 rm -f $O/*/*.db
 echo done

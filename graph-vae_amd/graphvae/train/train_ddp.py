@@ -260,8 +260,12 @@ class TrainStep:
         once), hence both halves only need the decoder's logits; they are joined before the
         step returns.  Results are bit-identical to the sequential order.
         `pipeline` (needs overlap_matching): the step returns WITHOUT that join, so the matching
-        half of step N also runs beside the model half, backward and Adam of step N+1 (two
-        workspaces alternate; a workspace is reused only after its matching has finished).
+        half of step N also runs beside the model half, backward and Adam of step N+1 (three
+        workspaces in rotation, `GVAE_PIPELINE_SLOTS` to change it; a workspace is reused only
+        after its matching has finished.  With two, the forward of step N+2 waits for the
+        assignment of step N, and the chain model half -> matching -> assignment of one step,
+        0.45 ms of dependent work plus three cross-stream waits at 256 graphs of 32 nodes on the
+        S-free path, bounds two steps: 0.30 ms per step against 0.25 ms with three).
         The returned loss tensor, `model.last_permutations()` and `loss_sum` are then valid on
         the current stream only after `wait()`; parameters, gradients and optimiser state never
         depend on the matching and are always in stream order.
@@ -281,7 +285,7 @@ class TrainStep:
         self._tail = None       # pipelined: third stream for assignment + losses
         self._ev_model = self._ev_match = self._ev_mpm = None
         self._slot = 0
-        self.n_slots = int(os.environ.get("GVAE_PIPELINE_SLOTS", "3"))
+        self.n_slots = max(2, int(os.environ.get("GVAE_PIPELINE_SLOTS", "3")))
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)

@@ -465,3 +465,60 @@ def test_eval_mode_backward_vs_cpu_restatement():
     out["loss"].backward()
     g_train = model.conv1.lin.weight.grad.cpu().numpy()
     assert np.abs(g_train - st["conv1.lin.weight"].grad.numpy()).max() > 1e-3 * np.abs(g_train).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,train", [(32, True), (40, True), (24, False)])
+def test_model_half_resident_kernel_equals_generic_kernel(N, train):
+    """The model half of the forward has a kernel that keeps a graph's activations in LDS (graphs
+    of at most 64 nodes, hidden width 128) and a generic one that stages them through global
+    memory; the first reads weight rows as 16-byte vectors, so a parameter buffer that starts
+    4 bytes off that alignment takes the generic one.  Same activations, logits and BatchNorm
+    statistics from both, to fp32 rounding of differently ordered sums."""
+    from graphvae.data import synthetic_batch
+    from graphvae.models import GraphVAE
+    B = 7
+    hb = synthetic_batch("enzymes", B, N, "deg", seed=21).to(DEV)
+    torch.manual_seed(5)
+    model = GraphVAE(1, 128, 64, N).to(DEV)
+    model.precompute_dataset_rho([hb])
+    model.train(train)
+    eng = model._engine_for(hb)
+    eps = torch.randn(B, 64, device=DEV)
+    flat = model.flat_parameters()
+    shifted = torch.empty(flat.numel() + 1, dtype=torch.float32, device=DEV)[1:]
+    shifted.copy_(flat)
+    assert flat.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    names = ("Ahat", "Y1", "H1", "Y2", "H2", "gvec", "mu", "logvar_raw", "vec_logits", "node_logits")
+    got = []
+    for params in (flat, shifted):
+        bn = model.bn_state().clone()
+        eng.forward_model(params, bn, hb, eps, model._pos_weight_dev(), train)
+        got.append({k: eng.debug_tensor(k, B) for k in names} | {"bn_state": bn})
+        eng.forward_match_loss()
+    for k in got[0]:
+        a, b = got[0][k], got[1][k]
+        scale = max(b.abs().max().item(), 1e-6)
+        # (BatchNorm divides by a per-graph standard deviation: rounding differences of its input
+        # come out amplified, 5e-6 of the scale of H2 on these batches)
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (k, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_accumulate_loss_entry_point():
+    """gvae_step_accumulate_loss: the float64 accumulator takes rec + beta * kl evaluated in fp32
+    (two roundings, as `out4[0] + beta * out4[1]` of the step-by-step path), the copy takes the
+    four scalars."""
+    from graphvae.engine import StepEngine
+    eng = StepEngine(1, 8, 4, 6, DEV)
+    out4 = torch.tensor([3.1415927, 0.57721566, 7.0, -2.0], dtype=torch.float32, device=DEV)
+    acc = torch.tensor([1.5], dtype=torch.float64, device=DEV)
+    copy = torch.zeros(4, dtype=torch.float32, device=DEV)
+    beta = 0.3
+    for _ in range(2):
+        eng.accumulate_loss(out4, beta, acc, copy=copy)
+    step = (out4[0] + beta * out4[1]).double().item()
+    assert acc.item() == 1.5 + step + step
+    assert torch.equal(copy, out4)
+    eng.accumulate_loss(out4, beta, acc)                  # the copy is optional
+    assert acc.item() == 1.5 + step + step + step
