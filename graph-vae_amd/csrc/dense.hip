@@ -753,7 +753,7 @@ __device__ __forceinline__ f32x16 tile_lds_w(const float *A, int as, int m0, con
                                              int n0, int K) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const float *ap = A + (m0 + r) * as + 4 * half;
-  const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(n0 + r) * K + 4 * half);
+  const float4 *wp = reinterpret_cast<const float4 *>(W + (n0 + r) * K + 4 * half);
   float4 bv[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u)
@@ -857,7 +857,7 @@ __device__ __forceinline__ float row_dot4(const float *in, const float *__restri
 }
 
 template <int NP>
-__global__ __launch_bounds__(NP * 8) void model_fwd_lds_kernel(ModelFwdArgs a) {
+__global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a) {
   constexpr int NT = NP * 8, NW = NT / 64;
   extern __shared__ __align__(16) float lds[];
   const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
@@ -1022,14 +1022,14 @@ __device__ __forceinline__ f32x16 tile_lds_wn(const float *A, int as, int m0, co
                                               int ldw, int n0, int K) {
   const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
   const float *ap = A + (m0 + r) * as + 4 * half;
-  const float *bp = W + (int64_t)(4 * half) * ldw + n0 + r;
+  const float *bp = W + (4 * half) * ldw + n0 + r;       // (a weight matrix: far below 2^31 floats)
   float4 bv[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (8 * u < K) {
-      bv[u].x = bp[(int64_t)(8 * u + 0) * ldw]; bv[u].y = bp[(int64_t)(8 * u + 1) * ldw];
-      bv[u].z = bp[(int64_t)(8 * u + 2) * ldw]; bv[u].w = bp[(int64_t)(8 * u + 3) * ldw];
+      bv[u].x = bp[(8 * u + 0) * ldw]; bv[u].y = bp[(8 * u + 1) * ldw];
+      bv[u].z = bp[(8 * u + 2) * ldw]; bv[u].w = bp[(8 * u + 3) * ldw];
     }
   }
   f32x16 acc = {0};
@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void bn_relu_bwd_lds(
 }
 
 template <int NP>
-__global__ __launch_bounds__(NP * 8) void model_bwd_lds_kernel(ModelBwdArgs a) {
+__global__ __launch_bounds__(NP * 8, 4) void model_bwd_lds_kernel(ModelBwdArgs a) {
   constexpr int NT = NP * 8, NW = NT / 64;
   extern __shared__ __align__(16) float lds[];
   const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
