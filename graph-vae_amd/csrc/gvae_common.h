@@ -32,8 +32,17 @@ constexpr size_t kMaxDynLds = 160 * 1024 - 1024;
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// gvae_match_stream in two parts (matching.hip): the streamed launch with the S-free tail either
-// run at once or left to match_stream_tail, which a caller may put on another stream behind it.
+// gvae_match_stream in parts (matching.hip): match_stream_run = match_stream_prep (similarity
+// tensor, first iteration), match_stream_iterate (the persistent streaming launch) and, if
+// run_tail, match_stream_tail (the S-free kernel for the graphs the launch handed over).  A caller
+// may enqueue the three separately, the tail on another stream behind the launch.
+int match_stream_prep(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                      float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
+int match_stream_iterate(const int32_t *d_R, int n_graphs, int r_max, int s_layout, const float *d_S,
+                         const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                         float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream);
 int match_stream_run(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                      int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                      const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,

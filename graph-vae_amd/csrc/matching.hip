@@ -2185,7 +2185,8 @@ int gvae::match_stream_tail(const float *d_A, const float *d_P, const float *d_N
                             int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
                             int64_t strideX, int iters, float tol, int early_stop,
                             int32_t *d_iters_done, void *d_ws, void *stream) {
-  if (!early_stop || iters <= 1 || n_graphs <= 0) return GVAE_OK;
+  // (the same conditions under which match_stream_iterate lets its launch set the flags)
+  if (!early_stop || iters <= 1 || n_graphs <= 0 || g_handoff_bytes <= 0) return GVAE_OK;
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "match_stream (tail): null pointer");
   const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
@@ -2200,11 +2201,12 @@ int gvae::match_stream_tail(const float *d_A, const float *d_P, const float *d_N
   return GVAE_OK;
 }
 
-int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
-                     int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
-                     const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
-                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, bool run_tail,
-                     void *stream) {
+// Similarity tensor and the first MPM iteration (computed from row maxima of S without reading
+// the tensor back): everything of a streamed matching that precedes the persistent launch.
+int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                            int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                            const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                            float tol, int early_stop, int32_t *d_iters_done, void *d_ws, void *stream) {
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_S && d_S_off && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "match_stream: null pointer");
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
@@ -2212,9 +2214,7 @@ int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS
                ld, ldx, iters);
   int rc = gvae_edge_sim(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, stream);
   if (rc) return rc;
-  if (n_graphs == 0 || iters == 0)
-    return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters,
-                             tol, early_stop, d_iters_done, d_ws, false, stream);
+  if (n_graphs == 0 || iters == 0) return GVAE_OK;
   GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "match_stream: more than 65535 graphs per call");
   const size_t r2 = (size_t)r_max * r_max;
   size_t lds = sizeof(float) * (kCtlFloats + ((r2 + 3) & ~(size_t)3) + 2 * (size_t)r_max);
@@ -2234,8 +2234,19 @@ int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS
   hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(r_max >= 48 ? 1024 : 256), lds, s, d_A,
                      d_P, d_NS, d_R, r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, a_in_lds,
                      d_iters_done, m.stop);
-  rc = check_launch("match_stream");
-  if (rc) return rc;
+  return check_launch("match_stream");
+}
+
+// Iterations 2..k of the graphs match_stream_prep left unconverged, by the persistent streaming
+// launch; with early stop it hands the latency-bound tail of graphs of at most 88 nodes to
+// match_stream_tail (flags in the workspace).
+int gvae::match_stream_iterate(const int32_t *d_R, int n_graphs, int r_max, int s_layout,
+                               const float *d_S, const int64_t *d_S_off, float *d_X, int ldx,
+                               int64_t strideX, int iters, float tol, int early_stop,
+                               int32_t *d_iters_done, void *d_ws, void *stream) {
+  if (n_graphs == 0 || iters == 0)
+    return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters,
+                             tol, early_stop, d_iters_done, d_ws, false, stream);
   if (iters == 1) return GVAE_OK;
   // Graphs small enough for the S-free kernel may be handed to it once the batch is bound by
   // the latency of an iteration rather than by HBM (see MpmQueue): same X, same iteration
@@ -2245,9 +2256,21 @@ int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS
   // streamed iteration of a graph that has the device to itself (19 us + its slab's transfer).
   const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
   const bool handoff = early_stop && g_handoff_bytes > 0 && r_cap > 0;
-  rc = mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
-                         early_stop, d_iters_done, d_ws, true, stream, true, handoff ? r_cap : 0);
-  if (rc || !handoff || !run_tail) return rc;
+  return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,
+                           early_stop, d_iters_done, d_ws, true, stream, true, handoff ? r_cap : 0);
+}
+
+int gvae::match_stream_run(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
+                     int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
+                     const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
+                     float tol, int early_stop, int32_t *d_iters_done, void *d_ws, bool run_tail,
+                     void *stream) {
+  int rc = match_stream_prep(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, d_X,
+                             ldx, strideX, iters, tol, early_stop, d_iters_done, d_ws, stream);
+  if (rc) return rc;
+  rc = match_stream_iterate(d_R, n_graphs, r_max, s_layout, d_S, d_S_off, d_X, ldx, strideX, iters, tol,
+                            early_stop, d_iters_done, d_ws, stream);
+  if (rc || !run_tail) return rc;
   return match_stream_tail(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, d_X, ldx, strideX, iters, tol,
                            early_stop, d_iters_done, d_ws, stream);
 }

@@ -374,67 +374,73 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
                               int phases, hipStream_t s) {
   const int B = n_graphs, Z = d->Z, N = d->N;
   const Workspace w = carve(d, B, (char *)d_ws);
-  const bool do_match = phases & GVAE_PHASE_MATCH, do_assign = phases & GVAE_PHASE_ASSIGN_LOSS;
+  const bool do_prep = phases & GVAE_PHASE_PREP, do_mpm = phases & GVAE_PHASE_MPM;
+  const bool do_tail = phases & GVAE_PHASE_TAIL, do_assign = phases & GVAE_PHASE_ASSIGN_LOSS;
   // model_legacy.py:294-310 matches all N rows of the padded matrices (no cut to the real nodes)
   const bool indiv = loss_variant == GVAE_LOSS_INDIVIDUAL_RHO;
   const int32_t *d_R_loss = d_R;
   if (indiv) {
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, w.r_full, B, N);
+    if (do_prep)
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, w.r_full, B, N);
     d_R = w.r_full;
     r_max = N;
   }
-  // One chunk of graphs of at most 32 nodes: the streamed matching leaves its S-free tail to the
-  // assignment phase (both phases are told the same chunk list)
-  const bool tail_deferred = matching == GVAE_MATCH_STREAM && n_chunks <= 1 && r_max <= 32;
+  // A streamed matching whose similarity tensor fits the S buffer whole runs as three parts a
+  // caller may enqueue separately (every call for a batch is told the same chunk list); a chunked
+  // one walks its chunks through the buffer in the MPM part, each chunk with its own tail at once
+  // (the chunks share the queue workspace)
+  const bool one_chunk = n_chunks <= 1;
+  const int64_t NN = (int64_t)N * N;
   // matching (model.py:312-323)
   if (matching == GVAE_MATCH_NONE) {
-    if (do_match) {
+    if (do_prep) {
       hipLaunchKernelGGL(identity_perm_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, s, d_perm, B, N);
       TRY(hipMemsetAsync(d_iters_done, 0, sizeof(int32_t) * B, s) == hipSuccess ? 0 : GVAE_ELAUNCH);
     }
-  } else if (do_match) {
-    TRY(launch_prob(w.vec, w.node, B, N, w.P, s));
-    TRY(gvae_node_sim(d_adj, w.P, d_R, B, N, (int64_t)N * N, w.NS, s));
-    hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
-                       w.X);
-    if (matching == GVAE_MATCH_STREAM) {
-      // chunk by chunk through the one S buffer (stream order keeps a chunk's matching
-      // ahead of the next chunk's overwrite)
-      const int32_t one_chunk[2] = {0, B};
-      const int32_t *cb = n_chunks > 0 ? h_chunk_begin : one_chunk;
-      const int nc = n_chunks > 0 ? n_chunks : 1;
-      const int64_t NN = (int64_t)N * N;
-      for (int c = 0; c < nc; ++c) {
-        const int g0 = cb[c], nb = cb[c + 1] - cb[c];
-        // One chunk of graphs of at most 32 nodes: the S-free tail is left to the assignment
-        // phase, which may run on another stream beside the next batch's similarity tensor
-        // (256 dense graphs of 32 nodes: 2.89 -> 2.81 ms per step).  Larger graphs' tail kernels
-        // (1024 threads, up to 67 KiB of LDS) find no room beside the next batch's persistent
-        // kernel and would hold back the assignment until that ends (ENZYMES-shaped batches of up
-        // to 40 / 126 nodes: 0.63 -> 0.74 and 2.67 -> 3.71 ms), so they run here, at once; so
-        // does every chunk of a chunked batch (the chunks share the queue workspace).
-        TRY(match_stream_run(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
-                             r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
-                             tol, early_stop, d_iters_done + g0, w.mpm_ws, !tail_deferred, s));
-      }
-    } else if (do_assign) {
-      // S-free MPM with the assignment as its epilogue
-      TRY(gvae_mpm_fused_assign(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N,
-                                (int64_t)N * N, mpm_iters, tol, early_stop, d_iters_done, d_perm, N,
-                                w.status, s));
-    } else {
-      TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
-                         mpm_iters, tol, early_stop, d_iters_done, s));
+  } else {
+    if (do_prep) {
+      TRY(launch_prob(w.vec, w.node, B, N, w.P, s));
+      TRY(gvae_node_sim(d_adj, w.P, d_R, B, N, NN, w.NS, s));
+      hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
+                         w.X);
+      if (matching == GVAE_MATCH_STREAM && one_chunk)
+        TRY(match_stream_prep(d_adj, w.P, w.NS, d_R, B, N, NN, r_max, GVAE_S_PADDED, d_S, d_S_off, w.X, N,
+                              NN, mpm_iters, tol, early_stop, d_iters_done, w.mpm_ws, s));
     }
+    if (do_mpm) {
+      if (matching == GVAE_MATCH_STREAM && one_chunk) {
+        TRY(match_stream_iterate(d_R, B, r_max, GVAE_S_PADDED, d_S, d_S_off, w.X, N, NN, mpm_iters, tol,
+                                 early_stop, d_iters_done, w.mpm_ws, s));
+      } else if (matching == GVAE_MATCH_STREAM) {
+        // chunk by chunk through the one S buffer (stream order keeps a chunk's matching
+        // ahead of the next chunk's overwrite)
+        for (int c = 0; c < n_chunks; ++c) {
+          const int g0 = h_chunk_begin[c], nb = h_chunk_begin[c + 1] - h_chunk_begin[c];
+          TRY(match_stream_run(d_adj + g0 * NN, w.P + g0 * NN, w.NS + g0 * NN, d_R + g0, nb, N, NN,
+                               r_max, GVAE_S_PADDED, d_S, d_S_off + g0, w.X + g0 * NN, N, NN, mpm_iters,
+                               tol, early_stop, d_iters_done + g0, w.mpm_ws, true, s));
+        }
+      } else if (do_assign) {
+        // S-free MPM with the assignment as its epilogue
+        TRY(gvae_mpm_fused_assign(d_adj, w.P, w.NS, d_R, B, N, NN, r_max, w.X, N, NN, mpm_iters, tol,
+                                  early_stop, d_iters_done, d_perm, N, w.status, s));
+      } else {
+        TRY(gvae_mpm_fused(d_adj, w.P, w.NS, d_R, B, N, NN, r_max, w.X, N, NN, mpm_iters, tol,
+                           early_stop, d_iters_done, s));
+      }
+    }
+    // The last iterations of the graphs the streaming launch handed over, by the S-free kernel.
+    // As a part of its own it can run on another stream beside the NEXT batch's similarity tensor,
+    // whose persistent launch the caller orders behind it: beside that launch the tail's kernels
+    // (up to 1024 threads and 67 KiB of LDS per graph) find no room and would hold back this
+    // batch's assignment until it ends.
+    if (do_tail && matching == GVAE_MATCH_STREAM && one_chunk)
+      TRY(match_stream_tail(d_adj, w.P, w.NS, d_R, B, N, NN, r_max, w.X, N, NN, mpm_iters, tol, early_stop,
+                            d_iters_done, w.mpm_ws, s));
   }
   if (!do_assign) return 0;
-  // (only then: the hand-off flags sit where a launch over all B graphs puts them, and a chunked
-  // matching, whose launches are smaller, neither writes nor clears that place)
-  if (tail_deferred)
-    TRY(match_stream_tail(d_adj, w.P, w.NS, d_R, B, N, (int64_t)N * N, r_max, w.X, N, (int64_t)N * N,
-                          mpm_iters, tol, early_stop, d_iters_done, w.mpm_ws, s));
   // assignment (model.py:319-323), unless the S-free MPM above has already done it
-  if (matching == GVAE_MATCH_STREAM || (matching == GVAE_MATCH_FUSED && !do_match))
+  if (matching == GVAE_MATCH_STREAM || (matching == GVAE_MATCH_FUSED && !do_mpm))
     TRY(gvae_lsap(w.X, N, (int64_t)N * N, d_R, B, r_max, d_perm, N, w.status, s));
   if (indiv) {
     TRY(launch_loss_fwd_indiv(w.vec, d_adj, w.mu, w.lvraw, d_perm, d_R_loss, B, N, Z, w.rec_i, w.kl_i,
@@ -517,7 +523,7 @@ int gvae_step_forward_match_loss(const gvae_dims *d, const float *d_adj, const i
                                  int phases, void *stream) {
   GVAE_REQUIRE(d && d_adj && d_R && d_pos_weight && d_ws && d_out4 && d_perm && d_iters_done,
                GVAE_EINVAL, "step_forward_match_loss: null pointer");
-  GVAE_REQUIRE(phases >= 1 && phases <= (GVAE_PHASE_MATCH | GVAE_PHASE_ASSIGN_LOSS), GVAE_EINVAL,
+  GVAE_REQUIRE(phases > 0 && !(phases & ~(GVAE_PHASE_MATCH | GVAE_PHASE_ASSIGN_LOSS)), GVAE_EINVAL,
                "step_forward_match_loss: phases=%d", phases);
   TRY(check_match_args(d, n_graphs, r_max, loss_variant, matching, d_S, d_S_off, h_chunk_begin,
                        n_chunks, "step_forward_match_loss"));

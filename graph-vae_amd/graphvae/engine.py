@@ -18,7 +18,10 @@ P_COUNT = 20
 MATCH_NONE, MATCH_STREAM, MATCH_FUSED = 0, 1, 2
 _MATCH = {"none": MATCH_NONE, "stream": MATCH_STREAM, "fused": MATCH_FUSED}
 LOSS_CURRENT, LOSS_DUMMY_MASKED, LOSS_INDIVIDUAL_RHO = 0, 1, 2   # GVAE_LOSS_* of the library
-PHASE_MATCH, PHASE_ASSIGN_LOSS = 1, 2    # GVAE_PHASE_* of the library
+# GVAE_PHASE_* of the library: the parts of the forward's second half, in their order
+PHASE_PREP, PHASE_MPM, PHASE_TAIL, PHASE_ASSIGN_LOSS = 4, 8, 16, 2
+PHASE_MATCH = PHASE_PREP | PHASE_MPM | PHASE_TAIL
+_PHASE_ORDER = (PHASE_PREP, PHASE_MPM, PHASE_TAIL, PHASE_ASSIGN_LOSS)
 
 # parameter tensors in flat-buffer order (reference module named_parameters() order)
 PARAM_NAMES = [
@@ -308,24 +311,29 @@ class StepEngine:
         [rec, kl, max_logit, logvar_max] (engine memory, valid once PHASE_ASSIGN_LOSS has run).
         The parameter gradients do not depend on the permutation (reference model.py:325-334
         gathers prediction and truth through the same permutation), so this may run concurrently
-        with `backward`.  `phases`: PHASE_MATCH (similarity tensor + MPM) and PHASE_ASSIGN_LOSS
-        (assignment + losses) may be enqueued by two calls, the second ordered behind the first
-        (possibly on another stream)."""
+        with `backward`.  `phases`: the parts PHASE_PREP (probabilities, node block, similarity
+        tensor, first iteration), PHASE_MPM (the remaining iterations), PHASE_TAIL (streamed
+        matching: the iterations left to the S-free kernel) and PHASE_ASSIGN_LOSS may be enqueued
+        by several calls, in this order, each ordered behind the one before (possibly on another
+        stream); PHASE_MATCH is the first three."""
         if self._pending is None:
             raise _hip.GvaeHipError("forward_match_loss called without a forward_model before it")
         B, r_max, mode, pos_weight, todo = self._pending
-        if phases & ~todo or not phases:
-            raise _hip.GvaeHipError(f"forward_match_loss: phases {phases} not outstanding ({todo})")
-        if (phases & PHASE_ASSIGN_LOSS) and (todo & PHASE_MATCH) and not (phases & PHASE_MATCH):
-            raise _hip.GvaeHipError("forward_match_loss: assignment requested before the matching")
+        want = [p for p in _PHASE_ORDER if phases & p]
+        if not want or phases & ~todo or [p for p in _PHASE_ORDER if todo & p][:len(want)] != want:
+            raise _hip.GvaeHipError(f"forward_match_loss: phases {phases} are not the next outstanding "
+                                    f"ones ({todo}; order: prep 4, mpm 8, tail 16, assign + loss 2)")
         batch, _eps, loss_variant = self._fwd_batch
         todo &= ~phases
         self._pending = (B, r_max, mode, pos_weight, todo) if todo else None
-        S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch, stream=stream)
-                                             if phases & PHASE_MATCH else (None, None, None, 0))
-        if mode == MATCH_STREAM and not (phases & PHASE_MATCH):
-            # (the buffer is validated, not used; the chunk list tells the assignment phase
-            # whether the matching left its S-free tail to it)
+        # (the first part plans the chunks and uploads their offsets, on its stream: the later
+        # parts are ordered behind it)
+        touches_S = phases & (PHASE_PREP | PHASE_MPM)
+        S_ptr, Soff_ptr, chunks, n_chunks = (self._S_args(mode, batch, stream=stream) if touches_S
+                                             else (None, None, None, 0))
+        if mode == MATCH_STREAM and not touches_S:
+            # (the buffer is validated, not used; the chunk list tells the later parts whether
+            # the matching ran as one chunk, i.e. left its S-free tail to PHASE_TAIL)
             S_ptr, Soff_ptr = self._S.data_ptr(), self._S_off.data_ptr()
             chunks, n_chunks = self._S_chunks, len(self._S_chunks) - 1
         _hip._check(self.L.gvae_step_forward_match_loss(

@@ -35,7 +35,7 @@ import yaml
 
 from ..data import (DenseGraphBatch, DenseLoader, GraphData, collate, graph_from_adjacency,
                     graph_from_networkx, synthetic_adjacencies)
-from ..engine import PHASE_ASSIGN_LOSS, PHASE_MATCH
+from ..engine import MATCH_STREAM, PHASE_ASSIGN_LOSS, PHASE_MATCH, PHASE_MPM, PHASE_PREP, PHASE_TAIL
 from ..models.model import GraphVAE
 
 SEED = 42
@@ -283,7 +283,8 @@ class TrainStep:
         self.pipeline = bool(pipeline) and self.overlap_matching
         self._side = None       # second stream + events, created on first use
         self._tail = None       # pipelined: third stream for assignment + losses
-        self._ev_model = self._ev_match = self._ev_mpm = None
+        self._fourth = None     # pipelined, streamed matching: the S-free tail of the matching
+        self._ev_model = self._ev_match = self._ev_mpm = self._ev_tail = self._ev_tail_last = None
         self._slot = 0
         self.n_slots = max(2, int(os.environ.get("GVAE_PIPELINE_SLOTS", "3")))
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
@@ -341,13 +342,17 @@ class TrainStep:
                 self._side = concurrent_stream(self.grads.device, tries=self.probe_tries)
                 self._ev_model = [torch.cuda.Event() for _ in range(self.n_slots)]
                 self._ev_mpm = [torch.cuda.Event() for _ in range(self.n_slots)]
+                self._ev_tail = [torch.cuda.Event() for _ in range(self.n_slots)]
+                self._ev_tail_last = None
                 self._ev_match = [None] * self.n_slots
                 if self.pipeline:
                     # assignment + losses of step N (one wavefront per graph, latency-bound) run
                     # beside the similarity tensor and the MPM of step N+1
                     self._tail = concurrent_stream(self.grads.device, others=[self._side],
                                                    tries=self.probe_tries)
-                for st in (self._side, self._tail):
+                    self._fourth = concurrent_stream(self.grads.device, others=[self._side, self._tail],
+                                                     tries=self.probe_tries)
+                for st in (self._side, self._tail, self._fourth):
                     # event waits between priority classes stalled the device (see concurrent_stream)
                     assert st is None or st.priority == 0, "side streams must have default priority"
             main = torch.cuda.current_stream(self.grads.device)
@@ -368,10 +373,29 @@ class TrainStep:
                 side.wait_event(self._ev_model[k])
                 if tail is None:
                     res, last = eng.forward_match_loss(stream=side), side
-                else:
+                elif getattr(eng, "last_mode", None) != MATCH_STREAM:
                     eng.forward_match_loss(PHASE_MATCH, stream=side)
                     self._ev_mpm[k].record(side)
                     tail.wait_event(self._ev_mpm[k])
+                    res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
+                else:
+                    # Streamed matching: the similarity tensor of this step is written while the
+                    # S-free tail of the previous step (a work-group per surviving graph, on the
+                    # third stream) still runs; the persistent launch waits for that tail, which
+                    # would find no room beside it
+                    eng.forward_match_loss(PHASE_PREP, stream=side)
+                    if self._ev_tail_last is not None:
+                        side.wait_event(self._ev_tail_last)
+                    eng.forward_match_loss(PHASE_MPM, stream=side)
+                    self._ev_mpm[k].record(side)
+                    # (a stream of its own: on the third one it would queue behind the previous
+                    # step's assignment, which runs beside this step's persistent launch and as long)
+                    fourth = self._fourth
+                    fourth.wait_event(self._ev_mpm[k])
+                    eng.forward_match_loss(PHASE_TAIL, stream=fourth)
+                    self._ev_tail[k].record(fourth)
+                    self._ev_tail_last = self._ev_tail[k]
+                    tail.wait_event(self._ev_tail[k])
                     res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
                 out = torch.empty_like(res)          # allocated on the current stream, written on `last`
                 out.record_stream(last)

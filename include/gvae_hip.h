@@ -276,15 +276,27 @@ int gvae_step_forward(const gvae_dims *d, const float *d_params, float *d_bn_sta
  * concurrently with gvae_step_backward of the same batch: it reads the logits, mu and logvar
  * and writes only buffers the backward never touches.  The caller joins the two streams
  * before it reads d_out4 / d_perm and before the next forward reuses the workspace.
- * Arguments as in gvae_step_forward.  `phases` selects what the call enqueues: GVAE_PHASE_MATCH
- * (similarity tensor and MPM), GVAE_PHASE_ASSIGN_LOSS (assignment, losses, diagnostics; after
- * the matching of the same batch) or both; a caller with a third stream lets the assignment
- * of one batch (one wavefront per graph, latency-bound) run beside the matching of the next.
- * Two calls for one batch must be given the same matching mode, r_max and chunk list: a streamed
- * matching of one chunk of graphs of at most 32 nodes leaves the last iterations of its slowest
- * graphs to the assignment phase. */
-#define GVAE_PHASE_MATCH 1
+ * Arguments as in gvae_step_forward.  `phases` selects what the call enqueues, a run of
+ * consecutive parts of
+ *   GVAE_PHASE_PREP         probabilities, node block, uniform X0; streamed matching of one chunk:
+ *                           also the similarity tensor and the first iteration
+ *   GVAE_PHASE_MPM          the remaining MPM iterations (streamed: the persistent launch; a
+ *                           chunked batch walks all its chunks through the S buffer here)
+ *   GVAE_PHASE_TAIL         streamed matching of one chunk with early stop: the last iterations of
+ *                           the slowest graphs, which the persistent launch leaves to the S-free
+ *                           kernel (nothing otherwise)
+ *   GVAE_PHASE_ASSIGN_LOSS  assignment, losses, diagnostics
+ * (GVAE_PHASE_MATCH = the first three).  Calls for one batch must come in this order, each ordered
+ * behind the one before (stream order or an event), with the same matching mode, r_max and chunk
+ * list.  A caller with a third stream lets tail + assignment of one batch (a work-group or a
+ * wavefront per graph, latency-bound) run beside the similarity tensor of the next batch, and
+ * orders the next batch's GVAE_PHASE_MPM behind this batch's GVAE_PHASE_TAIL: beside a persistent
+ * launch the tail's kernels find no room. */
 #define GVAE_PHASE_ASSIGN_LOSS 2
+#define GVAE_PHASE_PREP 4
+#define GVAE_PHASE_MPM 8
+#define GVAE_PHASE_TAIL 16
+#define GVAE_PHASE_MATCH (GVAE_PHASE_PREP | GVAE_PHASE_MPM | GVAE_PHASE_TAIL)
 int gvae_step_forward_model(const gvae_dims *d, const float *d_params, float *d_bn_state,
                             const float *d_x, const float *d_adj, const int32_t *d_n_x,
                             const int32_t *d_R, int n_graphs, const float *d_eps, int train,

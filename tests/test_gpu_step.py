@@ -215,6 +215,20 @@ def test_split_forward_phase_order_is_enforced(golden_dir):
     with pytest.raises(_hip.GvaeHipError):
         eng.forward_match_loss(PHASE_ASSIGN_LOSS)
     assert torch.equal(out, ref) and torch.equal(eng.perm, perm_ref)
+    # the matching in its three parts: no part before its predecessor, all four in order = forward
+    from graphvae.engine import PHASE_MPM, PHASE_PREP, PHASE_TAIL
+    args = (model.flat_parameters(), model.bn_state().clone(), batch, eps, model._pos_weight_dev(), True)
+    eng.forward_model(*args)
+    for early in (PHASE_MPM, PHASE_TAIL, PHASE_PREP | PHASE_TAIL, PHASE_MPM | PHASE_TAIL):
+        with pytest.raises(_hip.GvaeHipError):
+            eng.forward_match_loss(early)
+    eng.forward_match_loss(PHASE_PREP)
+    with pytest.raises(_hip.GvaeHipError):
+        eng.forward_match_loss(PHASE_TAIL)
+    eng.forward_match_loss(PHASE_MPM)
+    eng.forward_match_loss(PHASE_TAIL)
+    out = eng.forward_match_loss(PHASE_ASSIGN_LOSS).clone()
+    assert torch.equal(out, ref) and torch.equal(eng.perm, perm_ref)
 
 
 @pytest.mark.parametrize("matching", ["fused", "stream"])
