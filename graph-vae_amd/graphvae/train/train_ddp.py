@@ -380,8 +380,8 @@ class TrainStep:
                     res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
                 else:
                     # Streamed matching: the similarity tensor of this step is written while the
-                    # S-free tail of the previous step (a work-group per surviving graph, on the
-                    # third stream) still runs; the persistent launch waits for that tail, which
+                    # S-free tail of the previous step (a work-group per surviving graph, on a
+                    # stream of its own) still runs; the persistent launch waits for that tail, which
                     # would find no room beside it
                     eng.forward_match_loss(PHASE_PREP, stream=side)
                     if self._ev_tail_last is not None:
