@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void model_fwd_graph_kernel(ModelFwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// The same chain for graphs of at most 64 nodes and a hidden width of at most 128 (a multiple of
+// The same chain for graphs of at most 128 nodes and a hidden width of at most 128 (a multiple of
 // 32), with the graph's activations resident in LDS: every stage reads its operands from LDS (the
 // weights from L2) and leaves its result there for the next one; the copies in the workspace,
 // which the backward reads, are plain stores nobody waits for.  A stage then costs its arithmetic
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void model_fwd_graph_kernel(ModelFwdArgs a) {
 // ---------------------------------------------------------------------------
 struct FwdLds {
   int as, hs;                        // row strides (floats) of Ahat and of the activation buffers
-  int o_ah, o_b0, o_b1, o_vec;       // offsets in floats; the first 2 KiB per 256 threads are doubles
+  int o_ah, o_b, o_vec;              // offsets in floats; the first 2 KiB per 256 threads are doubles
   size_t bytes;
 };
 __host__ __device__ inline FwdLds fwd_lds_layout(int NP, int H, int Z) {
@@ -717,9 +717,8 @@ __host__ __device__ inline FwdLds fwd_lds_layout(int NP, int H, int Z) {
   L.as = NP + 4;
   L.hs = H + 4;
   L.o_ah = (NP * 8 / 256) * 512;     // after double sh[NT/256][4][64]
-  L.o_b0 = L.o_ah + NP * L.as;
-  L.o_b1 = L.o_b0 + NP * L.hs;
-  L.o_vec = L.o_b1 + NP * L.hs;      // dinv[NP], gvec[H], mu[Z], lv[Z], z[Z]
+  L.o_b = L.o_ah + NP * L.as;
+  L.o_vec = L.o_b + NP * L.hs;       // dinv[NP], gvec[H], mu[Z], lv[Z], z[Z]
   L.bytes = (size_t)(L.o_vec + NP + H + 3 * Z) * sizeof(float);
   return L;
 }
@@ -858,14 +857,14 @@ __device__ __forceinline__ float row_dot4(const float *in, const float *__restri
 
 template <int NP>
 __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a) {
-  constexpr int NT = NP * 8, NW = NT / 64;
+  constexpr int NT = NP * 8;
   extern __shared__ __align__(16) float lds[];
   const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const int N = a.N, F = a.F, H = a.H, Z = a.Z;
   const FwdLds L = fwd_lds_layout(NP, H, Z);
   const int AS = L.as, HS = L.hs;
   double *shd = reinterpret_cast<double *>(lds);
-  float *Ah = lds + L.o_ah, *b0 = lds + L.o_b0, *b1 = lds + L.o_b1;
+  float *Ah = lds + L.o_ah, *b = lds + L.o_b;
   float *dinv = lds + L.o_vec, *gv = dinv + NP, *mu_s = gv + H, *lv_s = mu_s + Z, *z_s = lv_s + Z;
   const int nx = a.n_x[g], R = a.R[g];
   const int64_t NH = (int64_t)N * H;
@@ -894,7 +893,7 @@ __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a
         for (int f = 0; f < F; ++f) acc = __fmaf_rn(xg[i * F + f], a.W1[c * F + f], acc);
         a.H0a[g * NH + e] = acc;
       }
-      b0[i * HS + c] = acc;
+      b[i * HS + c] = acc;
     }
   }
   __syncthreads();
@@ -914,28 +913,30 @@ __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a
     }
   }
   __syncthreads();
+  // One activation buffer, updated in place: a contraction's tiles (at most one per wavefront:
+  // (NP/32)(H/32) <= NP/8 wavefronts) are all computed before any is stored.
   const int tn = H / 32, tiles = (NP / 32) * tn;
-  // layer 1: Y1 = Ahat * H0a -> b1;  H1 = relu(bn(Y1 + bias)) -> b0
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    tile_store(tile_lds_lds(Ah, AS, m0, b0, HS, n0, NP), b1, HS, m0, n0, a.Y1 + g * NH, N, H);
-  }
+  const bool has_tile = wave < tiles;
+  const int m0 = (wave / tn) * 32, n0 = (wave % tn) * 32;
+  f32x16 acc;
+  // layer 1: Y1 = Ahat * H0a;  H1 = relu(bn(Y1 + bias))
+  if (has_tile) acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
   __syncthreads();
-  bn_relu_lds<NT>(b1, b0, HS, NP, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
+  if (has_tile) tile_store(acc, b, HS, m0, n0, a.Y1 + g * NH, N, H);
+  __syncthreads();
+  bn_relu_lds<NT>(b, b, HS, NP, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
                   a.mean1 + (int64_t)g * H, a.invstd1 + (int64_t)g * H, a.varu1 + (int64_t)g * H, shd);
   __syncthreads();
-  // layer 2: H0b = H1 * W2^T -> b1;  Y2 = Ahat * H0b -> b0;  H2 -> b1
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    tile_store(tile_lds_w(b0, HS, m0, a.W2, n0, H), b1, HS, m0, n0, a.H0b + g * NH, N, H);
-  }
+  // layer 2: H0b = H1 * W2^T;  Y2 = Ahat * H0b;  H2 = relu(bn(Y2 + bias))
+  if (has_tile) acc = tile_lds_w(b, HS, m0, a.W2, n0, H);
   __syncthreads();
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    tile_store(tile_lds_lds(Ah, AS, m0, b1, HS, n0, NP), b0, HS, m0, n0, a.Y2 + g * NH, N, H);
-  }
+  if (has_tile) tile_store(acc, b, HS, m0, n0, a.H0b + g * NH, N, H);
   __syncthreads();
-  bn_relu_lds<NT>(b0, b1, HS, NP, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
+  if (has_tile) acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
+  __syncthreads();
+  if (has_tile) tile_store(acc, b, HS, m0, n0, a.Y2 + g * NH, N, H);
+  __syncthreads();
+  bn_relu_lds<NT>(b, b, HS, NP, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
                   a.mean2 + (int64_t)g * H, a.invstd2 + (int64_t)g * H, a.varu2 + (int64_t)g * H, shd);
   __syncthreads();
   // pooled vector: the four row lanes of pool_fwd_body, in its order
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a
     for (int e = tid; e < 4 * H; e += NT) {
       const int rl = e / H, c = e - rl * H;
       float s = 0.0f;
-      for (int i = rl; i < nx; i += 4) s += b1[i * HS + c];
+      for (int i = rl; i < nx; i += 4) s += b[i * HS + c];
       shf[rl * 128 + c] = s;
     }
     __syncthreads();
@@ -990,8 +991,9 @@ int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
     hipLaunchKernelGGL(model_fwd_graph_kernel, dim3(B), dim3(256), 0, s, a);
     return check_launch("model_fwd_graph");
   }
-  const int NP = a.N <= 32 ? 32 : 64;
+  const int NP = a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 128);
   const size_t lds = fwd_lds_layout(NP, a.H, a.Z).bytes;
+  GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "model_fwd: %zu bytes of LDS", lds);
   auto launch = [&](auto kernel) -> int {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)kernel,
@@ -1002,7 +1004,9 @@ int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
     hipLaunchKernelGGL(kernel, dim3(B), dim3(NP * 8), lds, s, a);
     return check_launch("model_fwd_lds");
   };
-  return NP == 32 ? launch(model_fwd_lds_kernel<32>) : launch(model_fwd_lds_kernel<64>);
+  return NP == 32   ? launch(model_fwd_lds_kernel<32>)
+         : NP == 64 ? launch(model_fwd_lds_kernel<64>)
+                    : launch(model_fwd_lds_kernel<128>);
 }
 
 // ---------------------------------------------------------------------------
@@ -1061,42 +1065,62 @@ __device__ __forceinline__ void bn_relu_bwd_lds(
     const float b = cv ? bias[c] : 0.0f;
     const float mu = cv ? mean[c] : 0.0f;
     const float is = cv ? invstd[c] : 0.0f;
-    float xc[RP], dp[RP];
-#pragma unroll
-    for (int q = 0; q < RP; ++q) {
-      const int i = rl + 4 * q;
-      xc[q] = 0.0f;
-      dp[q] = 0.0f;
+    // a lane's rows stay in registers between the two passes while they fit (16 rows at most);
+    // the 32 rows of the largest size are read again (dsrc may be dst: a lane reads an element
+    // before it writes it)
+    constexpr int RC = RP <= 16 ? RP : 1;
+    float xc[RC], dp[RC];
+    auto load = [&](int i, float &x, float &d) {
+      x = 0.0f;
+      d = 0.0f;
       if (cv && i < nx) {
         const int e = i * H + c;
-        xc[q] = (Yg[e] + b) - mu;
-        const float d = dsrc ? dsrc[i * hs + c] : dgv[c] * inv_r;
-        dp[q] = Og[e] > 0.0f ? d : 0.0f;
+        x = (Yg[e] + b) - mu;
+        const float din = dsrc ? dsrc[i * hs + c] : dgv[c] * inv_r;
+        d = Og[e] > 0.0f ? din : 0.0f;
+      }
+    };
+    double sb = 0.0, dot = 0.0;
+    if constexpr (RP <= 16) {
+#pragma unroll
+      for (int q = 0; q < RP; ++q) load(rl + 4 * q, xc[q], dp[q]);
+#pragma unroll
+      for (int q = 0; q < RP; ++q)
+        if (rl + 4 * q < nx) {
+          sb += (double)dp[q];
+          dot += (double)dp[q] * (double)xc[q];
+        }
+    } else {
+      for (int i = rl; i < nx; i += 4) {
+        load(i, xc[0], dp[0]);
+        sb += (double)dp[0];
+        dot += (double)dp[0] * (double)xc[0];
       }
     }
-    double sb = 0.0, dot = 0.0;
-#pragma unroll
-    for (int q = 0; q < RP; ++q)
-      if (rl + 4 * q < nx) {
-        sb += (double)dp[q];
-        dot += (double)dp[q] * (double)xc[q];
-      }
     sb = quad_rows_sum(sb, sh, rl, cl);
     dot = quad_rows_sum(dot, sh, rl, cl);
     const float ga = cv ? gamma[c] : 0.0f;
     const float dmean = batch_stats ? (float)(sb / (double)nx) : 0.0f;
     const float k = batch_stats ? (float)(dot * (double)is * (double)is / (double)nx) : 0.0f;
     double sdy = 0.0;
-#pragma unroll
-    for (int q = 0; q < RP; ++q) {
-      const int i = rl + 4 * q;
+    auto emit = [&](int i, float x, float d) {
       float v = 0.0f;
-      if (i < nx) v = (dp[q] - dmean - xc[q] * k) * is * ga;
+      if (i < nx) v = (d - dmean - x * k) * is * ga;
       if (cv) {
         dst[i * hs + c] = v;
         if (dYg && i < N) dYg[(int64_t)i * H + c] = v;
       }
       sdy += (double)v;
+    };
+    if constexpr (RP <= 16) {
+#pragma unroll
+      for (int q = 0; q < RP; ++q) emit(rl + 4 * q, xc[q], dp[q]);
+    } else {
+#pragma unroll 2
+      for (int i = rl; i < NP; i += 4) {
+        load(i, xc[0], dp[0]);
+        emit(i, xc[0], dp[0]);
+      }
     }
     sdy = quad_rows_sum(sdy, sh, rl, cl);
     if (rl == 0 && cv) {
@@ -1109,14 +1133,14 @@ __device__ __forceinline__ void bn_relu_bwd_lds(
 
 template <int NP>
 __global__ __launch_bounds__(NP * 8, 4) void model_bwd_lds_kernel(ModelBwdArgs a) {
-  constexpr int NT = NP * 8, NW = NT / 64;
+  constexpr int NT = NP * 8;
   extern __shared__ __align__(16) float lds[];
   const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const int N = a.N, H = a.H, Z = a.Z;
   const FwdLds L = bwd_lds_layout(NP, H, Z);
   const int AS = L.as, HS = L.hs;
   double *shd = reinterpret_cast<double *>(lds);
-  float *Ah = lds + L.o_ah, *b0 = lds + L.o_b0, *b1 = lds + L.o_b1;
+  float *Ah = lds + L.o_ah, *b = lds + L.o_b;
   float *dhe_s = lds + L.o_vec, *dhn_s = dhe_s + H, *part = dhn_s + H;   // part[2H]
   float *zpart = part + 2 * H, *dmu_s = zpart + 2 * Z, *dlv_s = dmu_s + Z;
   const int nx = a.n_x[g], R = a.R[g];
@@ -1177,45 +1201,55 @@ __global__ __launch_bounds__(NP * 8, 4) void model_bwd_lds_kernel(ModelBwdArgs a
   }
   __syncthreads();
   const int tn = H / 32, tiles = (NP / 32) * tn;
-  // layer 2: pooling and BatchNorm + ReLU backward -> b0; dH0 = Ahat * dY -> b1 (Ahat is symmetric)
+  const bool has_tile = wave < tiles;
+  const int m0 = (wave / tn) * 32, n0 = (wave % tn) * 32;
+  f32x16 acc;
+  // layer 2: pooling and BatchNorm + ReLU backward;  dH0 = Ahat * dY (Ahat is symmetric)
   bn_relu_bwd_lds<NT, NP>(nullptr, dgv, 1.0f / (float)R, a.Y2 + g * NH, a.H2 + g * NH, a.b2, a.g2,
-                          a.mean2 + gH, a.invstd2 + gH, nx, N, H, batch_stats, b0, HS, nullptr,
+                          a.mean2 + gH, a.invstd2 + gH, nx, N, H, batch_stats, b, HS, nullptr,
                           a.dgam2 + gH, a.dbet2 + gH, a.dbias2 + gH, shd);
   __syncthreads();
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    tile_store(tile_lds_lds(Ah, AS, m0, b0, HS, n0, NP), b1, HS, m0, n0, a.dH0_2 + g * NH, N, H);
-  }
+  if (has_tile) acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
   __syncthreads();
-  // layer 1: dH1 = dH0 * W2 -> b0; BatchNorm + ReLU backward -> b1; dH0 = Ahat * dY
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    const f32x16 acc = tile_lds_wn(b1, HS, m0, a.W2, H, n0, H);
+  if (has_tile) tile_store(acc, b, HS, m0, n0, a.dH0_2 + g * NH, N, H);
+  __syncthreads();
+  // layer 1: dH1 = dH0 * W2;  BatchNorm + ReLU backward;  dH0 = Ahat * dY
+  if (has_tile) acc = tile_lds_wn(b, HS, m0, a.W2, H, n0, H);
+  __syncthreads();
+  if (has_tile) {
     const int lane = tid & 63, col = n0 + (lane & 31);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      b0[(m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * HS + col] = acc[q];
+      b[(m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * HS + col] = acc[q];
   }
   __syncthreads();
-  bn_relu_bwd_lds<NT, NP>(b0, nullptr, 0.0f, a.Y1 + g * NH, a.H1 + g * NH, a.b1, a.g1, a.mean1 + gH,
-                          a.invstd1 + gH, nx, N, H, batch_stats, b1, HS, a.dY + g * NH, a.dgam1 + gH,
+  bn_relu_bwd_lds<NT, NP>(b, nullptr, 0.0f, a.Y1 + g * NH, a.H1 + g * NH, a.b1, a.g1, a.mean1 + gH,
+                          a.invstd1 + gH, nx, N, H, batch_stats, b, HS, a.dY + g * NH, a.dgam1 + gH,
                           a.dbet1 + gH, a.dbias1 + gH, shd);
   __syncthreads();
-  for (int t = wave; t < tiles; t += NW) {
-    const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
-    tile_store(tile_lds_lds(Ah, AS, m0, b1, HS, n0, NP), b0, HS, m0, n0, a.dH0_1 + g * NH, N, H);
+  if (has_tile) {
+    acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
+    // (the last result goes to the workspace only)
+    float *glob = a.dH0_1 + g * NH;
+    const int lane = tid & 63, col = n0 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (row < N) glob[(int64_t)row * H + col] = acc[q];
+    }
   }
 }
 
 bool model_chain_resident(int N, int H, int Z) {
-  return N <= 64 && H <= 128 && H % 32 == 0 && Z % 4 == 0 && Z <= 128;
+  return N <= 128 && H <= 128 && H % 32 == 0 && Z % 4 == 0 && Z <= 128;
 }
 
 int launch_model_bwd_graph(const ModelBwdArgs &a, int B, hipStream_t s) {
   GVAE_REQUIRE(model_chain_resident(a.N, a.H, a.Z), GVAE_ELIMIT,
                "model_bwd: sizes outside the LDS-resident kernel (N=%d H=%d Z=%d)", a.N, a.H, a.Z);
-  const int NP = a.N <= 32 ? 32 : 64;
+  const int NP = a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 128);
   const size_t lds = bwd_lds_layout(NP, a.H, a.Z).bytes;
+  GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "model_bwd: %zu bytes of LDS", lds);
   auto launch = [&](auto kernel) -> int {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)kernel,
@@ -1226,7 +1260,9 @@ int launch_model_bwd_graph(const ModelBwdArgs &a, int B, hipStream_t s) {
     hipLaunchKernelGGL(kernel, dim3(B), dim3(NP * 8), lds, s, a);
     return check_launch("model_bwd_lds");
   };
-  return NP == 32 ? launch(model_bwd_lds_kernel<32>) : launch(model_bwd_lds_kernel<64>);
+  return NP == 32   ? launch(model_bwd_lds_kernel<32>)
+         : NP == 64 ? launch(model_bwd_lds_kernel<64>)
+                    : launch(model_bwd_lds_kernel<128>);
 }
 
 // dmu = dz + ck * mu / Z ;  dlv = dz * eps * 0.5 * exp(0.5 lv) - ck * 0.5 * (1 - exp(lv)) / Z,

@@ -482,10 +482,10 @@ def test_eval_mode_backward_vs_cpu_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,train", [(32, True), (40, True), (24, False)])
+@pytest.mark.parametrize("N,train", [(32, True), (40, True), (24, False), (100, True)])
 def test_model_half_resident_kernel_equals_generic_kernel(N, train):
     """The model half of the forward has a kernel that keeps a graph's activations in LDS (graphs
-    of at most 64 nodes, hidden width 128) and a generic one that stages them through global
+    of at most 128 nodes, hidden width 128) and a generic one that stages them through global
     memory; the first reads weight rows as 16-byte vectors, so a parameter buffer that starts
     4 bytes off that alignment takes the generic one.  Same activations, logits and BatchNorm
     statistics from both, to fp32 rounding of differently ordered sums."""
