@@ -1,6 +1,6 @@
 # sweep of the tail hand-off threshold of the streamed matching (MiB of live similarity tensors)
-for w in c2 c3; do
-for mb in 0 32 64 128 256 512 1024; do
+for w in ${WORKLOADS:-c2 c3}; do
+for mb in ${SIZES:-0 32 64 128 256 512 1024}; do
   echo -n "$w handoff $mb MiB: "
   GVAE_HANDOFF_MB=$mb timeout -k 10 200 python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-fused-leg 2>/dev/null | python3 -c "
 import json,sys

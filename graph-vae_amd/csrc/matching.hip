@@ -2336,8 +2336,10 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
   // batch (no resume) was measured and is not used: 0.40 -> 0.51 and 1.64 -> 2.16 ms per step
   // with the S-free matching, whose launch then waits for hardware queues it shares with the
   // step's other streams.
-  constexpr int kClasses = 5;
-  const int hi[kClasses] = {32, 44, 64, kFusedByteMaskMaxNodes, GVAE_MAX_NODES_LDS};
+  // (graphs of at most 44 nodes share the 512-thread shape: one class more would be one more
+  // stream, and the streams of a process share four hardware queues with the caller's own)
+  constexpr int kClasses = 4;
+  const int hi[kClasses] = {44, 64, kFusedByteMaskMaxNodes, GVAE_MAX_NODES_LDS};
   int top = 0;
   while (top + 1 < kClasses && hi[top] < r_max) ++top;
   int rc = GVAE_OK;
