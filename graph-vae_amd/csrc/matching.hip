@@ -1871,34 +1871,6 @@ static inline size_t mpm_fused_lds_bytes(int r_max) {
 }
 constexpr size_t kMaxFusedLds = kMaxDynLds;
 
-// Streams and events of the library's own, per device, for launches that fork from the caller's
-// stream and join it again (created at first use; never destroyed: they live as long as the
-// process, like the device's primary context).
-#define GVAE_CLASS_DEVICES 64
-struct ClassStreams {
-  hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ready = false;
-};
-static std::mutex g_class_mu;
-static ClassStreams g_class_streams[GVAE_CLASS_DEVICES];
-static int class_streams(ClassStreams **out, const char *who) {
-  int dev = -1;
-  GVAE_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GVAE_CLASS_DEVICES, GVAE_ELAUNCH,
-               "%s: cannot identify the current device", who);
-  std::lock_guard<std::mutex> lk(g_class_mu);
-  ClassStreams &c = g_class_streams[dev];
-  if (!c.ready) {
-    bool ok = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 4 && ok; ++k)
-      ok = hipStreamCreateWithFlags(&c.st[k], hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming) == hipSuccess;
-    GVAE_REQUIRE(ok, GVAE_ELAUNCH, "%s: cannot create the class streams on device %d", who, dev);
-    c.ready = true;
-  }
-  *out = &c;
-  return GVAE_OK;
-}
 static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                             int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
                             int64_t strideX, int iters, float tol, int early_stop,
@@ -2300,7 +2272,6 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
   if (n_graphs == 0) return GVAE_OK;
   hipStream_t s = (hipStream_t)stream;
   ProfileScope ps(F_MPM_FUSED, s);
-  hipStream_t on = s;             // stream of the next launch
   auto launch = [&](auto kernel, int nt) -> int {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)kernel,
@@ -2308,7 +2279,7 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
       GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, lds,
                    hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel, dim3(n_graphs), dim3(nt), lds, on, d_A, d_P, d_NS, d_R, ld, stride, d_X,
+    hipLaunchKernelGGL(kernel, dim3(n_graphs), dim3(nt), lds, s, d_A, d_P, d_NS, d_R, ld, stride, d_X,
                        ldx, strideX, iters, tol, early_stop, d_iters_done, d_perm, n_perm, d_status,
                        d_resume, r_lo, r_hi);
     return GVAE_OK;
@@ -2322,51 +2293,15 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
     if (rm <= kFusedByteMaskMaxNodes) return launch(mpm_fused_kernel<1024, 8>, 1024);
     return launch(mpm_fused_kernel<1024, 16>, 1024);
   };
-  if (d_resume == nullptr) {
-    const int rc1 = pick(r_max);
-    return rc1 ? rc1 : check_launch(who);
-  }
-  // Resumed graphs (the tail of the streamed matching) run in the kernel shape of their own size
-  // class: one launch per class up to the batch's largest, each over all graphs (the work-groups
-  // of graphs outside the class, or not handed over, leave at once).  The classes do not depend
-  // on each other: the largest goes to the caller's stream, the others to streams of the
-  // library's own that fork from it and join it again, so the tail takes as long as its slowest
-  // class instead of the sum over classes (ENZYMES-shaped batches of up to 40 / 126 nodes:
-  // 0.63 -> 0.52 and 2.69 -> 2.44 ms per streamed step).  The same split for a whole ragged
-  // batch (no resume) was measured and is not used: 0.40 -> 0.51 and 1.64 -> 2.16 ms per step
-  // with the S-free matching, whose launch then waits for hardware queues it shares with the
-  // step's other streams.
-  // (graphs of at most 44 nodes share the 512-thread shape: one class more would be one more
-  // stream, and the streams of a process share four hardware queues with the caller's own)
-  constexpr int kClasses = 4;
-  const int hi[kClasses] = {44, 64, kFusedByteMaskMaxNodes, GVAE_MAX_NODES_LDS};
-  int top = 0;
-  while (top + 1 < kClasses && hi[top] < r_max) ++top;
-  int rc = GVAE_OK;
-  ClassStreams *cs = nullptr;
-  std::unique_lock<std::mutex> lk(g_class_mu, std::defer_lock);
-  if (top > 0) {
-    rc = class_streams(&cs, who);
-    if (rc) return rc;
-    lk.lock();                    // the fork / join events are shared by the callers on a device
-    GVAE_REQUIRE(hipEventRecord(cs->fork, s) == hipSuccess, GVAE_ELAUNCH, "%s: event record failed", who);
-  }
-  for (int c = top; c >= 0 && !rc; --c) {
-    r_lo = c == 0 ? INT32_MIN : hi[c - 1] + 1;
-    r_hi = r_max < hi[c] ? r_max : hi[c];
-    lds = mpm_fused_lds_bytes(r_hi);
-    on = c == top ? s : cs->st[c];
-    if (c != top)
-      GVAE_REQUIRE(hipStreamWaitEvent(on, cs->fork, 0) == hipSuccess, GVAE_ELAUNCH,
-                   "%s: stream wait failed", who);
-    rc = pick(r_hi);
-    if (!rc && c != top)
-      GVAE_REQUIRE(hipEventRecord(cs->join[c], on) == hipSuccess &&
-                       hipStreamWaitEvent(s, cs->join[c], 0) == hipSuccess,
-                   GVAE_ELAUNCH, "%s: join failed", who);
-  }
-  if (rc) return rc;
-  return check_launch(who);
+  // Resumed graphs (the tail of the streamed matching; at most kFusedByteMaskMaxNodes nodes) all
+  // run in ONE launch, in the kernel shape of the largest: the tail takes as long as its slowest
+  // graph, which is one of the large ones, whatever shape the small ones run in.  One launch per
+  // size class on streams of the library's own, forked from and joined to the caller's stream, was
+  // faster when the streams found hardware queues of their own (ENZYMES-shaped batches of up to
+  // 126 nodes: 2.09 against 2.13 ms per step) and slower when they shared one with the caller's
+  // streams, a process has four (2.29 ms; batches of up to 40 nodes: 0.43-0.57 against 0.41 ms).
+  const int rc1 = pick(r_max);
+  return rc1 ? rc1 : check_launch(who);
 }
 
 int gvae_mpm_fused(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
