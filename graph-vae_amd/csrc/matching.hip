@@ -1922,8 +1922,9 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   const int64_t n_items = mpm_queue_cap(n_graphs, r_max);
   q.cap = (unsigned)n_items;
   const int64_t strideXnew = (int64_t)ldx * ldx;
-  GVAE_REQUIRE(hipMemsetAsync(q.words, 0, 512, s) == hipSuccess &&
-                   hipMemsetAsync(q.slots, 0, 8 * (size_t)n_items, s) == hipSuccess,
+  // (the queue words and the ring slots are adjacent in the workspace: one fill)
+  GVAE_REQUIRE(reinterpret_cast<char *>(q.slots) == reinterpret_cast<char *>(q.words) + 512 &&
+                   hipMemsetAsync(q.words, 0, 512 + 8 * (size_t)n_items, s) == hipSuccess,
                GVAE_ELAUNCH, "mpm_stream: memset failed");
   // Work-group size.  256 threads (several work-groups per CU, whose per-item phases overlap)
   // stream faster than 1024 at every size whose rows are not a multiple of 128 bytes -- steady
