@@ -1,4 +1,4 @@
-# round-2 measurement set: bench lines of every single-GPU workload, the c4 iteration sweep,
+# measurement set behind profiles/r2_*: bench lines of every single-GPU workload, the c4 iteration sweep,
 # rocprofv3 kernel stats of the default line's two legs, PMC traffic of the streaming kernel
 # (FETCH_SIZE and WRITE_SIZE in separate passes)
 set -e
