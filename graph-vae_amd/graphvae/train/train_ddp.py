@@ -243,7 +243,7 @@ class TrainStep:
     def __init__(self, model: GraphVAE, lr: float, weight_decay: float, clip_max: float,
                  world: int = 1, group=None, sync_bn_buffers: bool = False, engine=None,
                  force_collectives: bool = False, overlap_matching: bool = True,
-                 pipeline: bool = False, probe_tries: int = 4) -> None:
+                 pipeline: bool = False, probe_tries: int = 4, slots: int | None = None) -> None:
         """`engine`: object with StepEngine's forward / backward / adam_step; defaults to the
         model's HIP engine (tests inject a CPU checker to exercise the collective pattern).
         `sync_bn_buffers`: broadcast rank 0's BatchNorm running statistics before every forward,
@@ -261,7 +261,7 @@ class TrainStep:
         step returns.  Results are bit-identical to the sequential order.
         `pipeline` (needs overlap_matching): the step returns WITHOUT that join, so the matching
         half of step N also runs beside the model half, backward and Adam of step N+1 (three
-        workspaces in rotation, `GVAE_PIPELINE_SLOTS` to change it; a workspace is reused only
+        workspaces in rotation: `slots`, or the environment's GVAE_PIPELINE_SLOTS; a workspace is reused only
         after its matching has finished.  With two, the forward of step N+2 waits for the
         assignment of step N, and the chain model half -> matching -> assignment of one step,
         0.45 ms of dependent work plus three cross-stream waits at 256 graphs of 32 nodes on the
@@ -288,7 +288,7 @@ class TrainStep:
         self._ev_acc_last = self._acc_stream_last = None
         self._ev_model = self._ev_match = self._ev_mpm = self._ev_tail = self._ev_tail_last = None
         self._slot = 0
-        self.n_slots = max(2, int(os.environ.get("GVAE_PIPELINE_SLOTS", "3")))
+        self.n_slots = max(2, int(slots if slots is not None else os.environ.get("GVAE_PIPELINE_SLOTS", "3")))
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)
