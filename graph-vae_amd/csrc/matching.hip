@@ -907,9 +907,9 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
                                                               int32_t *__restrict__ iters_done,
                                                               const int32_t *__restrict__ first_stop,
                                                               int iters) {
-  // first_stop != nullptr: the first iteration has been done already (mpm_first_iter_kernel):
-  // iters_done holds 1, and a graph that converged in it, or whose budget is one iteration,
-  // gets no items
+  // first_stop != nullptr: the first iteration (mpm_first_iter_kernel), and for small graphs the
+  // second (edge_sim_iter_kernel), have been done already: iters_done holds their count, and a
+  // graph that converged in them, or whose budget they were, gets no items
   __shared__ int s_part[1024];
   __shared__ int s_live[1024];
   const int tid = threadIdx.x;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     const int R = Rarr[g];
     if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
     if (R <= 0 || R > r_max) { shape = 0; return 0; }
-    if (first_stop && ((first_stop[g] & 1) != 0 || iters <= 1)) { shape = 0; return 0; }
+    if (first_stop && ((first_stop[g] & 1) != 0 || iters_done[g] >= iters)) { shape = 0; return 0; }
     shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high, q.item_cap_kb);
     return mpm_shape_items(R, shape);
   };
@@ -1076,6 +1076,167 @@ __global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
     for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
     iters_done[g] = 1;
     stop[g] = ((early_stop && d < tol) ? 1 : 0) | (binary_ok ? 2 : 0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Similarity tensor AND the MPM iteration that would read it first.  The work-group that
+// produces the slab S[i,:,:,:] holds every element in a register on its way to memory, so it
+// also takes row i of the iteration on the X that mpm_first_iter_kernel left:
+//   T[j,a] = max_b S[i,j,a,b]*X[j,b],   Xn[i,a] = X[i,a]*NS[i,a] + canonical column sum of T
+// (the arithmetic of one item of the streaming kernel: the maximum is exact in any order, the
+// sum and the update are the same expressions), and the tensor is read once less.  Graphs of at
+// most kSimIterMaxNodes nodes that have not converged and have more than one iteration to
+// run (X and T of a graph have to fit LDS several times per CU: the kernel is bound by its
+// stores and needs the wavefronts); the others get the plain producer.  mpm_second_norm_kernel
+// finishes the iteration per graph.
+// ---------------------------------------------------------------------------
+constexpr int kSimIterMaxNodes = 64;
+
+__device__ __forceinline__ bool sim_iter_applies(int R, int stop_word, int iters) {
+  return R <= kSimIterMaxNodes && (stop_word & 1) == 0 && iters >= 2;
+}
+
+template <int V>
+__device__ __forceinline__ void edge_sim_iter_body(const float *__restrict__ Pg,
+                                                   const float *__restrict__ NSg, int ld, int R, int RS,
+                                                   int i, float *__restrict__ slab, const float *arow,
+                                                   const float *Xs, float *T) {
+  const int tid = threadIdx.x;
+  const int64_t plane = (int64_t)R * RS;
+  const int cols = RS / V;                      // <= 16 lanes per row at these sizes
+  const int rows_per_pass = 256 / cols;
+  const int rslot = tid / cols, c = tid - rslot * cols;
+  // lanes of a row are adjacent: a power-of-two group folds its maxima with DPP moves, any other
+  // width through an LDS maximum
+  const bool pow2 = (cols & (cols - 1)) == 0;
+  int lg = 0;
+  while ((1 << lg) < cols) ++lg;
+  if (rslot >= rows_per_pass) return;
+  for (int a = rslot; a < R; a += rows_per_pass) {
+    float p[V], d[V];
+    const float nsv = NSg[(int64_t)i * ld + a];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int b = min(c * V + v, R - 1);      // padding repeats the row's last element
+      p[v] = (b == a) ? 0.0f : Pg[(int64_t)a * ld + b];
+      d[v] = (b == a) ? nsv : 0.0f;
+    }
+    float *dst = slab + (int64_t)a * RS + c * V;
+    const float *xp = Xs + c * V;
+    for (int j = 0; j < R; ++j, dst += plane, xp += RS) {
+      const float aij = arow[j];
+      float o[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) o[v] = (j == i) ? d[v] : aij * p[v];
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      } else if constexpr (V == 2) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+      } else {
+        dst[0] = o[0];
+      }
+      float t = o[0] * xp[0];
+#pragma unroll
+      for (int v = 1; v < V; ++v) t = fmaxf(t, o[v] * xp[v]);
+      if (pow2) {
+        t = group_max(t, lg);
+        if (c == 0) T[j * R + a] = t;
+      } else {
+        __hip_atomic_fetch_max(&T[j * R + a], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_sim_iter_kernel(
+    const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
+    const int32_t *__restrict__ Rarr, int ld, int64_t stride, int layout, float *__restrict__ S,
+    const int64_t *__restrict__ S_off, const float *__restrict__ X, int ldx, int64_t strideX,
+    float *__restrict__ Xnew, int64_t strideXnew, const int32_t *__restrict__ stop, int iters) {
+  __shared__ float arow[1024];
+  extern __shared__ __attribute__((aligned(16))) float sim_lds[];
+  const int g = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const int R = Rarr[g];
+  if (i >= R) return;
+  const int RS = s_row_stride(R, layout);
+  const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
+  float *slab = S + S_off[g] + (int64_t)i * R * R * RS;
+  for (int j = tid; j < R; j += 256) arow[j] = (j == i) ? 1.0f : Ag[(int64_t)i * ld + j];
+  if (!sim_iter_applies(R, stop[g], iters)) {
+    __syncthreads();
+    if ((RS & 3) == 0) edge_sim_body<4>(Pg, NSg, ld, R, RS, i, slab, arow);
+    else if ((RS & 1) == 0) edge_sim_body<2>(Pg, NSg, ld, R, RS, i, slab, arow);
+    else edge_sim_body<1>(Pg, NSg, ld, R, RS, i, slab, arow);
+    return;
+  }
+  float *Xs = sim_lds;              // R rows of RS floats, the padding repeats the last element
+  float *T = sim_lds + R * RS;      // R*R
+  const float *Xg = X + g * strideX;
+  for (int e = tid; e < R * RS; e += 256) {
+    const int r = e / RS, cc = e - r * RS;
+    Xs[e] = Xg[(int64_t)r * ldx + min(cc, R - 1)];
+  }
+  for (int e = tid; e < R * R; e += 256) T[e] = -INFINITY;
+  __syncthreads();
+  if ((RS & 3) == 0) edge_sim_iter_body<4>(Pg, NSg, ld, R, RS, i, slab, arow, Xs, T);
+  else if ((RS & 1) == 0) edge_sim_iter_body<2>(Pg, NSg, ld, R, RS, i, slab, arow, Xs, T);
+  else edge_sim_iter_body<1>(Pg, NSg, ld, R, RS, i, slab, arow, Xs, T);
+  __syncthreads();
+  float *Xn = Xnew + g * strideXnew;
+  for (int pcol = tid; pcol < R; pcol += 256) {
+    // the row j == i does not take part in the sum: an exact +0 at its position
+    const float et = column_sum([&](int jj) { return jj == i ? 0.0f : T[jj * R + pcol]; }, pcol, R);
+    Xn[i * R + pcol] = Xs[i * RS + pcol] * NSg[(int64_t)i * ld + pcol] + et;
+  }
+}
+
+// Second half of the iteration edge_sim_iter_kernel started: canonical norm, X = Xn / norm,
+// convergence test, as the last arriver of a graph does in the streaming kernel.  One
+// work-group per graph; graphs the producer did not iterate are left alone.
+__global__ __launch_bounds__(256) void mpm_second_norm_kernel(
+    const int32_t *__restrict__ Rarr, int r_max, float *__restrict__ X, int ldx, int64_t strideX,
+    const float *__restrict__ Xnew, int64_t strideXnew, float tol, int early_stop, int iters,
+    int32_t *__restrict__ iters_done, int32_t *__restrict__ stop) {
+  extern __shared__ __attribute__((aligned(16))) float nrm_lds[];
+  __shared__ float red[4];
+  __shared__ float s_nrm;
+  const int g = blockIdx.x, tid = threadIdx.x, nt = 256;
+  const int R = Rarr[g];
+  if (R <= 0 || R > r_max || !sim_iter_applies(R, stop[g], iters)) return;
+  const int R2 = R * R;
+  float *T = nrm_lds;
+  float *Xg = X + g * strideX;
+  const float *Xn = Xnew + g * strideXnew;
+  for (int e = tid; e < R2; e += nt) T[e] = Xn[e];
+  __syncthreads();
+  const int n8 = R2 & ~7;
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8) acc = norm_chain(T, n8, tid, acc);
+    const float nrm = norm_finish(acc, T + n8, R2 - n8);
+    if (tid == 0) s_nrm = nrm;
+  }
+  __syncthreads();
+  const float nrm = s_nrm;
+  float dmax = 0.f;
+  bool isnan_any = false;
+  for (int e = tid; e < R2; e += nt) {
+    const float v = T[e] / nrm;
+    const int r = e / R, c = e - r * R;
+    const float d = fabsf(v - Xg[(int64_t)r * ldx + c]);
+    isnan_any |= (d != d);
+    dmax = fmaxf(dmax, d);
+    Xg[(int64_t)r * ldx + c] = v;
+  }
+  if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
+  dmax = wave_max(dmax);
+  if ((tid & 63) == 0) red[tid >> 6] = dmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    iters_done[g] = 2;
+    if (early_stop && d < tol) stop[g] |= 1;
   }
 }
 
@@ -2185,10 +2346,12 @@ int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_N
   GVAE_REQUIRE(n_graphs >= 0 && r_max > 0 && r_max <= ld && r_max <= ldx && iters >= 0, GVAE_EINVAL,
                "match_stream: bad sizes (n_graphs=%d r_max=%d ld=%d ldx=%d iters=%d)", n_graphs, r_max,
                ld, ldx, iters);
-  int rc = gvae_edge_sim(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, stream);
-  if (rc) return rc;
-  if (n_graphs == 0 || iters == 0) return GVAE_OK;
+  if (n_graphs == 0 || iters == 0)
+    return gvae_edge_sim(d_A, d_P, d_NS, d_R, n_graphs, ld, stride, r_max, s_layout, d_S, d_S_off, stream);
   GVAE_REQUIRE(n_graphs <= 65535, GVAE_ELIMIT, "match_stream: more than 65535 graphs per call");
+  GVAE_REQUIRE(d_S && ((uintptr_t)d_S & 15) == 0 && r_max <= 1024 &&
+                   (s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED),
+               GVAE_EINVAL, "match_stream: S must be 16-byte aligned, its layout dense or padded");
   const size_t r2 = (size_t)r_max * r_max;
   size_t lds = sizeof(float) * (kCtlFloats + ((r2 + 3) & ~(size_t)3) + 2 * (size_t)r_max);
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "match_stream: r_max=%d needs %zu bytes of LDS", r_max,
@@ -2207,6 +2370,20 @@ int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_N
   hipLaunchKernelGGL(mpm_first_iter_kernel, dim3(n_graphs), dim3(r_max >= 48 ? 1024 : 256), lds, s, d_A,
                      d_P, d_NS, d_R, r_max, ld, stride, d_X, ldx, strideX, tol, early_stop, a_in_lds,
                      d_iters_done, m.stop);
+  // the tensor, and with it the second iteration of the graphs small enough (X and T of the
+  // largest of them in LDS: at most 33 KiB per work-group)
+  const int rf = r_max < kSimIterMaxNodes ? r_max : kSimIterMaxNodes;
+  const size_t lds_sim = sizeof(float) * ((size_t)rf * ((rf + 3) & ~3) + (size_t)rf * rf);
+  {
+    ProfileScope ps(F_EDGE_SIM, s);
+    hipLaunchKernelGGL(edge_sim_iter_kernel, dim3(r_max, n_graphs), dim3(256), lds_sim, s, d_A, d_P,
+                       d_NS, d_R, ld, stride, s_layout, d_S, d_S_off, d_X, ldx, strideX, m.Xnew,
+                       (int64_t)ldx * ldx, m.stop, iters);
+  }
+  if (iters >= 2)
+    hipLaunchKernelGGL(mpm_second_norm_kernel, dim3(n_graphs), dim3(256), sizeof(float) * (size_t)rf * rf,
+                       s, d_R, r_max, d_X, ldx, strideX, m.Xnew, (int64_t)ldx * ldx, tol, early_stop,
+                       iters, d_iters_done, m.stop);
   return check_launch("match_stream");
 }
 

@@ -476,12 +476,14 @@ def test_match_stream_tail_handoff(hip):
             for g, rr in enumerate(Rh):
                 assert torch.equal(X[g, :rr, :rr], X_ref[g, :rr, :rr]), (name, g)
             streamed[name] = hip.mpm_stream_stats(ws.data_ptr())
-        # iteration 1 comes from the first-iteration kernel; the rest was streamed ...
-        assert streamed["off"] == (int((per_gi * (it - 1)).sum()), int((it - 1).sum()))
+        # iteration 1 comes from the first-iteration kernel, iteration 2 of graphs of at most 64
+        # nodes from the kernel that writes the tensor; the rest was streamed ...
+        rest = it - np.minimum(it, np.where(r <= 64, 2, 1))
+        assert streamed["off"] == (int((per_gi * rest).sum()), int(rest.sum()))
         # ... or, handed off at once, one streamed iteration per graph of at most 88 nodes that
-        # needed a second one (larger graphs and the weighted graph are never handed off)
+        # needed one (larger graphs and the weighted graph are never handed off)
         keep = (np.arange(len(Rh)) == 4) | (r > 88)
-        one = np.where(keep, it - 1, np.minimum(it - 1, 1))
+        one = np.where(keep, rest, np.minimum(rest, 1))
         assert streamed["always"] == (int((per_gi * one).sum()), int(one.sum()))
         assert streamed["always"][1] <= streamed["default"][1] <= streamed["off"][1]
         assert it[4] > 2 and it.max() > 10
