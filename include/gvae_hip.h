@@ -120,10 +120,13 @@ int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layou
  * tensor is written as by gvae_edge_sim; the FIRST iteration is computed without reading it
  * back: with a uniform X0, max_b S[i,j,a,b]*x0 = (max_b S[i,j,a,b])*x0 exactly (rounding is
  * monotone), and the row maximum of S is max(0, A[i,j]*max_{b!=a} P[a,b]) (the minimum over b
- * when A[i,j] < 0), so that iteration costs O(R^3) per graph instead of one pass over S; every
- * later iteration streams S, except those of the latency-bound tail, which the S-free kernel
- * takes over (gvae_set_stream_handoff_bytes).  d_X is output only.  Same X, same iteration
- * counts as the two calls, bit for bit.  d_ws: gvae_mpm_stream_ws_bytes. */
+ * when A[i,j] < 0), so that iteration costs O(R^3) per graph instead of one pass over S.  The
+ * SECOND iteration of a graph of at most 64 nodes is taken by the kernel that writes the tensor,
+ * from the values on their way to memory (the work-group that produces S[i,:,:,:] computes row
+ * i of the update), which saves the first pass over S.  Every later iteration streams S, except
+ * those of the latency-bound tail, which the S-free kernel takes over
+ * (gvae_set_stream_handoff_bytes).  d_X is output only.  Same X, same iteration counts as the
+ * two calls, bit for bit.  d_ws: gvae_mpm_stream_ws_bytes. */
 int gvae_match_stream(const float *d_A, const float *d_P, const float *d_NS, const int32_t *d_R,
                       int n_graphs, int ld, int64_t stride, int r_max, int s_layout, float *d_S,
                       const int64_t *d_S_off, float *d_X, int ldx, int64_t strideX, int iters,
