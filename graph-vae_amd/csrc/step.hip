@@ -401,8 +401,11 @@ static int forward_match_loss(const gvae_dims *d, const float *d_adj, const int3
     if (do_prep) {
       TRY(launch_prob(w.vec, w.node, B, N, w.P, s));
       TRY(gvae_node_sim(d_adj, w.P, d_R, B, N, NN, w.NS, s));
-      hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R, N,
-                         w.X);
+      // (the streamed matching computes its first iteration from the constant x0 and writes X
+      // itself: the uniform start is only read by the S-free kernel, or when nothing iterates)
+      if (matching != GVAE_MATCH_STREAM || mpm_iters < 1)
+        hipLaunchKernelGGL(x0_init_kernel, dim3(min(ceil_div(N * N, 256), 64), B), dim3(256), 0, s, d_R,
+                           N, w.X);
       if (matching == GVAE_MATCH_STREAM && one_chunk)
         TRY(match_stream_prep(d_adj, w.P, w.NS, d_R, B, N, NN, r_max, GVAE_S_PADDED, d_S, d_S_off, w.X, N,
                               NN, mpm_iters, tol, early_stop, d_iters_done, w.mpm_ws, s));
