@@ -1085,16 +1085,31 @@ __global__ __launch_bounds__(1024) void mpm_first_iter_kernel(
 // also takes row i of the iteration on the X that mpm_first_iter_kernel left:
 //   T[j,a] = max_b S[i,j,a,b]*X[j,b],   Xn[i,a] = X[i,a]*NS[i,a] + canonical column sum of T
 // (the arithmetic of one item of the streaming kernel: the maximum is exact in any order, the
-// sum and the update are the same expressions), and the tensor is read once less.  Graphs of at
-// most kSimIterMaxNodes nodes that have not converged and have more than one iteration to
-// run (X and T of a graph have to fit LDS several times per CU: the kernel is bound by its
-// stores and needs the wavefronts); the others get the plain producer.  mpm_second_norm_kernel
-// finishes the iteration per graph.
+// sum and the update are the same expressions), and the tensor is read once less.  For graphs
+// that have not converged and have more than one iteration to run; the others get the plain
+// producer.  The kernel is bound by its stores and needs its wavefronts, so LDS is kept small:
+// up to kSimIterMaxNodes nodes X and T of the graph are resident (33 KiB at 64 nodes); above, T
+// covers the few columns `a` the work-group has in flight and X is staged 16 rows at a time
+// (13 KiB at 128 nodes).  mpm_second_norm_kernel finishes the iteration per graph.
 // ---------------------------------------------------------------------------
 constexpr int kSimIterMaxNodes = 64;
+constexpr int kSimIterRowBlock = 16;
+// Between the two the plain producer stays: on ragged batches (ENZYMES-shaped, up to 82 nodes)
+// the launch lasts as long as its few largest slabs, which the second form writes 15-25 % slower
+// (3.3 against 3.9 TB/s at 82 nodes), more than the pass over their tensors it saves (producer
+// 0.14 -> 0.22 ms, streaming launch 0.95 -> 0.93 ms); dense batches of 96-128 nodes gain 6 %.
+constexpr int kSimIterBigMinNodes = 89;
 
 __device__ __forceinline__ bool sim_iter_applies(int R, int stop_word, int iters) {
-  return R <= kSimIterMaxNodes && (stop_word & 1) == 0 && iters >= 2;
+  return (R <= kSimIterMaxNodes || R >= kSimIterBigMinNodes) && (stop_word & 1) == 0 && iters >= 2;
+}
+// floats of dynamic LDS a work-group of edge_sim_iter_kernel needs for a graph of R nodes whose
+// rows of S hold RS floats (vectors of 4, 2 or 1 floats: see the kernel's dispatch)
+__host__ __device__ inline size_t sim_iter_lds_floats(int R, int RS) {
+  if (R <= kSimIterMaxNodes) return (size_t)R * RS + (size_t)R * R;
+  const int V = (RS & 3) == 0 ? 4 : (RS & 1) == 0 ? 2 : 1;
+  const int cols = RS / V;                                // lanes per row, < 256 at these sizes
+  return (size_t)kSimIterRowBlock * RS + (size_t)R * (256 / cols);
 }
 
 template <int V>
@@ -1149,6 +1164,87 @@ __device__ __forceinline__ void edge_sim_iter_body(const float *__restrict__ Pg,
   }
 }
 
+// The same for a graph whose X and T do not fit beside many other work-groups: the columns `a`
+// are taken rows_per_pass at a time (T holds those columns only), the rows of X in blocks of
+// kSimIterRowBlock.  Every thread of the work-group runs every barrier.
+template <int V>
+__device__ __forceinline__ void edge_sim_iter_big_body(
+    const float *__restrict__ Pg, const float *__restrict__ NSg, int ld, int R, int RS, int i,
+    float *__restrict__ slab, const float *arow, const float *__restrict__ Xg, int ldx,
+    float *__restrict__ Xn_row, float *Xb, float *T) {
+  const int tid = threadIdx.x;
+  const int64_t plane = (int64_t)R * RS;
+  const int cols = RS / V;
+  const int rpp = 256 / cols;                   // columns a in flight
+  const int rslot = tid / cols, c = tid - rslot * cols;
+  const bool lane_on = rslot < rpp;
+  const bool pow2 = (cols & (cols - 1)) == 0;
+  int lg = 0;
+  while ((1 << lg) < cols) ++lg;
+  for (int a0 = 0; a0 < R; a0 += rpp) {
+    const int a = a0 + rslot;
+    const bool act = lane_on && a < R;
+    float p[V], d[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { p[v] = 0.0f; d[v] = 0.0f; }
+    if (act) {
+      const float nsv = NSg[(int64_t)i * ld + a];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int b = min(c * V + v, R - 1);
+        p[v] = (b == a) ? 0.0f : Pg[(int64_t)a * ld + b];
+        d[v] = (b == a) ? nsv : 0.0f;
+      }
+    }
+    for (int e = tid; e < R * rpp; e += 256) T[e] = -INFINITY;
+    float *dst = slab + (int64_t)a * RS + c * V;
+    for (int j0 = 0; j0 < R; j0 += kSimIterRowBlock) {
+      const int jn = min(kSimIterRowBlock, R - j0);
+      __syncthreads();                                    // the previous block of X is used up
+      for (int e = tid; e < jn * RS; e += 256) {
+        const int jj = e / RS, cc = e - jj * RS;
+        Xb[e] = Xg[(int64_t)(j0 + jj) * ldx + min(cc, R - 1)];
+      }
+      __syncthreads();
+      if (act) {
+        for (int jj = 0; jj < jn; ++jj) {
+          const int j = j0 + jj;
+          const float aij = arow[j];
+          float o[V];
+#pragma unroll
+          for (int v = 0; v < V; ++v) o[v] = (j == i) ? d[v] : aij * p[v];
+          float *dj = dst + (int64_t)j * plane;
+          if constexpr (V == 4) {
+            *reinterpret_cast<float4 *>(dj) = make_float4(o[0], o[1], o[2], o[3]);
+          } else if constexpr (V == 2) {
+            *reinterpret_cast<float2 *>(dj) = make_float2(o[0], o[1]);
+          } else {
+            dj[0] = o[0];
+          }
+          const float *xp = Xb + jj * RS + c * V;
+          float t = o[0] * xp[0];
+#pragma unroll
+          for (int v = 1; v < V; ++v) t = fmaxf(t, o[v] * xp[v]);
+          if (pow2) {
+            t = group_max(t, lg);
+            if (c == 0) T[j * rpp + rslot] = t;
+          } else {
+            __hip_atomic_fetch_max(&T[j * rpp + rslot], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < rpp && a0 + tid < R) {
+      const int pcol = a0 + tid;
+      // the row j == i does not take part in the sum: an exact +0 at its position
+      const float et = column_sum([&](int jj) { return jj == i ? 0.0f : T[jj * rpp + tid]; }, pcol, R);
+      Xn_row[pcol] = Xg[(int64_t)i * ldx + pcol] * NSg[(int64_t)i * ld + pcol] + et;
+    }
+    __syncthreads();                                      // T is reset for the next columns
+  }
+}
+
 __global__ __launch_bounds__(256) void edge_sim_iter_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
     const int32_t *__restrict__ Rarr, int ld, int64_t stride, int layout, float *__restrict__ S,
@@ -1170,9 +1266,19 @@ __global__ __launch_bounds__(256) void edge_sim_iter_kernel(
     else edge_sim_body<1>(Pg, NSg, ld, R, RS, i, slab, arow);
     return;
   }
+  const float *Xg = X + g * strideX;
+  if (R > kSimIterMaxNodes) {
+    float *Xb = sim_lds;                               // kSimIterRowBlock rows of RS floats
+    float *Tb = sim_lds + kSimIterRowBlock * RS;       // R rows of (columns in flight) floats
+    float *Xn_row = Xnew + g * strideXnew + (int64_t)i * R;
+    __syncthreads();
+    if ((RS & 3) == 0) edge_sim_iter_big_body<4>(Pg, NSg, ld, R, RS, i, slab, arow, Xg, ldx, Xn_row, Xb, Tb);
+    else if ((RS & 1) == 0) edge_sim_iter_big_body<2>(Pg, NSg, ld, R, RS, i, slab, arow, Xg, ldx, Xn_row, Xb, Tb);
+    else edge_sim_iter_big_body<1>(Pg, NSg, ld, R, RS, i, slab, arow, Xg, ldx, Xn_row, Xb, Tb);
+    return;
+  }
   float *Xs = sim_lds;              // R rows of RS floats, the padding repeats the last element
   float *T = sim_lds + R * RS;      // R*R
-  const float *Xg = X + g * strideX;
   for (int e = tid; e < R * RS; e += 256) {
     const int r = e / RS, cc = e - r * RS;
     Xs[e] = Xg[(int64_t)r * ldx + min(cc, R - 1)];
@@ -2372,8 +2478,22 @@ int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_N
                      d_iters_done, m.stop);
   // the tensor, and with it the second iteration of the graphs small enough (X and T of the
   // largest of them in LDS: at most 33 KiB per work-group)
-  const int rf = r_max < kSimIterMaxNodes ? r_max : kSimIterMaxNodes;
-  const size_t lds_sim = sizeof(float) * ((size_t)rf * ((rf + 3) & ~3) + (size_t)rf * rf);
+  // (LDS for whichever graph of at most r_max nodes needs most)
+  size_t sim_floats = 0;
+  for (int r = 1; r <= r_max; ++r) {
+    const size_t need = sim_iter_lds_floats(r, s_row_stride(r, s_layout));
+    sim_floats = need > sim_floats ? need : sim_floats;
+  }
+  const size_t lds_sim = sizeof(float) * sim_floats;
+  const size_t lds_norm = sizeof(float) * (size_t)r_max * r_max;
+  GVAE_REQUIRE(lds_sim <= kMaxDynLds && lds_norm <= kMaxDynLds, GVAE_ELIMIT,
+               "match_stream: r_max=%d needs %zu bytes of LDS", r_max, lds_norm);
+  if (lds_norm > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)mpm_second_norm_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_norm);
+    GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "match_stream: cannot reserve %zu bytes of LDS: %s",
+                 lds_norm, hipGetErrorString(e));
+  }
   {
     ProfileScope ps(F_EDGE_SIM, s);
     hipLaunchKernelGGL(edge_sim_iter_kernel, dim3(r_max, n_graphs), dim3(256), lds_sim, s, d_A, d_P,
@@ -2381,7 +2501,7 @@ int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_N
                        (int64_t)ldx * ldx, m.stop, iters);
   }
   if (iters >= 2)
-    hipLaunchKernelGGL(mpm_second_norm_kernel, dim3(n_graphs), dim3(256), sizeof(float) * (size_t)rf * rf,
+    hipLaunchKernelGGL(mpm_second_norm_kernel, dim3(n_graphs), dim3(256), lds_norm,
                        s, d_R, r_max, d_X, ldx, strideX, m.Xnew, (int64_t)ldx * ldx, tol, early_stop,
                        iters, d_iters_done, m.stop);
   return check_launch("match_stream");

@@ -121,7 +121,7 @@ int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layou
  * back: with a uniform X0, max_b S[i,j,a,b]*x0 = (max_b S[i,j,a,b])*x0 exactly (rounding is
  * monotone), and the row maximum of S is max(0, A[i,j]*max_{b!=a} P[a,b]) (the minimum over b
  * when A[i,j] < 0), so that iteration costs O(R^3) per graph instead of one pass over S.  The
- * SECOND iteration of a graph of at most 64 nodes is taken by the kernel that writes the tensor,
+ * SECOND iteration of a graph of at most 64 or at least 89 nodes is taken by the kernel that writes the tensor,
  * from the values on their way to memory (the work-group that produces S[i,:,:,:] computes row
  * i of the update), which saves the first pass over S.  Every later iteration streams S, except
  * those of the latency-bound tail, which the S-free kernel takes over
