@@ -211,7 +211,7 @@ def test_match_stream_first_iteration_shortcut(hip, iters, es):
     graphs, odd sizes and graphs that converge in the first iteration."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(17)
-    sizes = (1, 2, 3, 5, 9, 16, 21, 32, 33, 47, 50, 64, 1, 70)
+    sizes = (1, 2, 3, 5, 9, 16, 21, 32, 33, 47, 50, 64, 1, 70, 89, 90, 96)
     As, Ps = [], []
     for k, R in enumerate(sizes):
         w = rng.normal(0.5, 1.0, (R, R)).astype(np.float32) * (rng.random((R, R)) < 0.5)
