@@ -3,13 +3,19 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c5] [--matching stream|fused]
 
-One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE for N > 1).  A step is one
+One process per GPU.  Under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this
+process is one rank; without it, `--gpus N` with N > 1 makes this process a launcher that starts N
+fresh rank processes itself before it touches the GPU (one worker per GPU, as the reference
+trainer spawns them, graphvae/train/train_ddp.py:417-421), forwards rank 0's JSON line as its
+only stdout and exits with the first non-zero rank status.  A step is one
 full optimisation step on one batch of synthetic graphs already resident in HBM: encoder,
 heads, decoder, matching (similarity tensor + MPM), assignment, losses, backward, gradient
 all-reduce (RCCL), clipping and Adam.  Rank 0 prints ONE JSON line.
 
-Workloads (BASELINE.json configs).  c2 keeps the per-GPU batch fixed ("scaling": "weak"); the
-others divide their global batch over the ranks ("strong"):
+Workloads (BASELINE.json configs).  By default c2 keeps the per-GPU batch fixed ("scaling":
+"weak") and the others divide their global batch over the ranks ("strong"); `--scaling` selects
+either for any workload (weak: every GPU gets the configuration's whole batch, strong: the
+configuration's batch is divided over the GPUs):
   c1  ENZYMES-shaped graphs of at most 40 nodes (reference configs/enzymes_deg.yaml:5), batch 32:
       the reference's own CPU-runnable configuration
   c2  dense graphs, max_nodes 32, batch 256 per GPU         (default; matching-dominated)
@@ -64,17 +70,73 @@ def parse():
     ap.add_argument("--matching", choices=["stream", "fused"], default="stream")
     ap.add_argument("--mpm-iters", type=int, default=50)
     ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: per-GPU batch fixed as --gpus grows; strong: global batch fixed "
+                         "(default: weak for c2, strong for the other workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-leg", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+def scaling_of(args) -> str:
+    return args.scaling or ("weak" if WORKLOADS[args.workload][2] is None else "strong")
+
+
+def per_gpu_batch(workload: str, scaling: str, world: int) -> int:
+    """Graphs per GPU and step: the configuration's batch on every GPU (weak) or divided
+    over the GPUs (strong)."""
+    config_batch = WORKLOADS[workload][2] or 256
+    return config_batch if scaling == "weak" else max(1, config_batch // world)
+
+
+def launch_ranks(n: int) -> int:
+    """Launcher for `--gpus N` outside torchrun: N fresh rank processes of this script, one per
+    GPU, started before this process has made any GPU call.  Rank 0's stdout (the JSON line) is
+    this process's stdout; the other ranks' stdout goes to stderr.  Returns the exit status."""
+    import socket
+    import subprocess
+    backend = os.environ.get("GVAE_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()          # counts devices without initialising them
+    if n_dev == 0:
+        print("bench.py needs a GPU (the HIP step has no CPU fallback)", file=sys.stderr)
+        return 2
+    if backend == "nccl" and n > n_dev:
+        print(f"bench.py: --gpus {n} but only {n_dev} visible GPU(s): RCCL needs one GPU per rank "
+              "(GVAE_DIST_BACKEND=gloo rehearses more ranks than GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:                # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            try:
+                code = procs[r].wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks",
+                      file=sys.stderr)
+                for q in pending:              # exactly the processes started above
+                    procs[q].terminate()
+    return rc
+
+
 def make_model_and_batches(args, rank, world, device, matching, n_batches=2):
     from graphvae.data import synthetic_batch
     from graphvae.models import GraphVAE
     kind, N, global_batch, early_stop = WORKLOADS[args.workload]
-    per_gpu = args.per_gpu_batch or (256 if global_batch is None else max(1, global_batch // world))
+    per_gpu = args.per_gpu_batch or per_gpu_batch(args.workload, scaling_of(args), world)
     torch.manual_seed(42)
     model = GraphVAE(1, 128, 64, N, matching=matching, mpm_iters=args.mpm_iters,
                      mpm_early_stop=early_stop)
@@ -156,10 +218,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))       # this process stays off the GPU
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP step has no CPU fallback)")
     # one GPU per rank; GVAE_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 code path
@@ -267,15 +329,18 @@ def main():
                 assert streamed_gi == float(np.sum(args.mpm_iters - not_streamed)), (streamed_gi, len(r))
             achieved = alg_bytes / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else 0.0
             # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as gfx950 needs,
-            # + WRITE_SIZE), measured with rocprofv3 on this workload's kernel and stored per
-            # executed graph-iteration in profiles/pmc_traffic.json; counters cannot be read
-            # from inside this process, so the stored figure is scaled to this run's iterations
+            # + WRITE_SIZE), measured with rocprofv3 on this workload's kernel and stored in
+            # profiles/pmc_traffic.json as the ratio of counted to algorithmic bytes of the
+            # profiled launches; counters cannot be read from inside this process, so that
+            # ratio is applied to the bytes the kernel counted itself in this run (a ragged
+            # batch has no fixed size per graph-iteration to scale by)
             traffic, traffic_src = None, None
             try:
                 pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json")).get(args.workload)
                 if pmc:
-                    traffic = pmc["hbm_bytes_per_graph_iteration"] * streamed_gi / max(1, n_iter)
-                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    traffic = pmc["ratio_to_algorithmic"] * alg_bytes / max(1, n_iter)
+                    traffic_src = ("profiles/pmc_traffic.json ratio_to_algorithmic (rocprofv3 --pmc FETCH_SIZE / "
+                                   "WRITE_SIZE, separate passes) x the bytes this run's kernel counted")
             except OSError:
                 pass
             roof = {"kernel": "mpm_stream_kernel", "bound": "hbm", "achieved": achieved,
@@ -287,6 +352,17 @@ def main():
                     "streamed_iters_per_graph": streamed_gi / (args.steps * per_gpu),
                     "tail_sfree_ms_per_step": ms_tail / max(1, args.steps),
                     "edge_sim_GBps": (float(np.sum(4.0 * r ** 4)) / (ms_es * 1e-3) / 1e9) if ms_es > 0 else None}
+            # step-level matching figure: algorithmic bytes of the kernel that writes the tensor
+            # (4 R^4 written + 8 R^2 read per graph) plus those of the streaming kernel, over the
+            # time of both
+            es_bytes = float(np.sum(4.0 * r ** 4 + 8.0 * r ** 2))
+            ms_both = ms_es + ms_iter
+            both = (es_bytes + alg_bytes) / (ms_both * 1e-3) / 1e9 if ms_both > 0 else 0.0
+            roof["matching_step"] = {"kernels": "edge_sim(+fused second iteration) + mpm_stream_kernel",
+                                     "bound": "hbm", "achieved": both, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": both / HBM_PEAK_GBS,
+                                     "alg_bytes_per_step": (es_bytes + alg_bytes) / max(1, args.steps),
+                                     "ms_per_step": ms_both / max(1, args.steps)}
         fused_roof = None
         if leg == "fused":
             # the S-free kernel is bound by vector fp32 work (4 R^3 flop per graph-iteration, operands
@@ -316,7 +392,9 @@ def main():
     line = {
         "metric": "training graphs/sec", "value": main_leg["value"], "unit": "graphs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak" if global_batch is None else "strong",
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": scaling_of(args),
+        "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        "backend": dist.get_backend() if dist.is_initialized() else None,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic {kind} graphs, max_nodes={N}, "
                                f"batch {main_leg['per_gpu_batch']} per GPU, deg features, hid 128, z 64, "
