@@ -2004,6 +2004,254 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   }
 }
 
+// LDS layout of mpm_fused_big_kernel, in floats after the control words: P as in FusedLds, ONE
+// region that holds X, then the row maxima M, then the new X in the norm's layout, and byte masks.
+struct FusedBigLds {
+  int PS, XS, TS, MB;
+  int off_XM, off_mask, total;
+};
+__host__ __device__ inline FusedBigLds fused_big_lds_layout(int R) {
+  FusedBigLds L;
+  const int R4 = (R + 3) & ~3;
+  L.PS = R4 + ((R4 & 7) == 4 ? 0 : 4);
+  L.XS = R4;
+  const int cnt = (R * R) >> 3;
+  L.TS = ((cnt + 27) & ~31) + 4;
+  L.MB = (R + 15) & ~15;
+  L.off_XM = R * L.PS;
+  const int xm = R * L.XS > 8 * L.TS ? R * L.XS : 8 * L.TS;
+  L.off_mask = L.off_XM + ((xm + 3) & ~3);
+  L.total = L.off_mask + R * L.MB / 4;
+  return L;
+}
+
+// S-free MPM for launches whose largest graph has 89..128 nodes: 1024 threads, one work-group per
+// graph, same recurrence and roundings as mpm_fused_kernel.  P, X and the row maxima M of a
+// 128-node graph do not fit in 160 KiB side by side, so M takes X's place: a lane keeps the (up
+// to sixteen) maxima it produces in registers until every lane has finished reading X, then they
+// are stored over it; the new X goes through registers the same way into the norm's layout over
+// M, and the normalised X back over that.  The current X, which the update also needs
+// element-wise (X[i,a] * NS[i,a], and the convergence test), is read back from the caller's X
+// buffer, where its owner lane stored it the iteration before (it stays in L2).
+constexpr int kBigNT = 1024, kBigRows = 16, kBigItems = 4;
+__global__ __launch_bounds__(kBigNT) void mpm_fused_big_kernel(
+    const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
+    const int32_t *__restrict__ Rarr, int ld, int64_t stride, float *__restrict__ X, int ldx,
+    int64_t strideX, int iters, float tol, int early_stop, int32_t *__restrict__ iters_done,
+    int64_t *__restrict__ perm, int n_perm, int32_t *__restrict__ status,
+    const int32_t *__restrict__ resume, int r_lo, int r_hi) {
+  {
+    const int Rg = Rarr[blockIdx.x];
+    if (Rg < r_lo || Rg > r_hi || (resume != nullptr && resume[blockIdx.x] == 0)) return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float *red = lds_all;                                  // [2][16]
+  float &s_nrm = lds_all[32];
+  float *Ttail = lds_all + 36;                           // [8]
+  float *lds = lds_all + kFusedCtl;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  constexpr int nt = kBigNT;
+  const int R = Rarr[g];
+  if (R <= 0) {
+    if (tid == 0) iters_done[g] = 0;
+    if (perm) {
+      for (int k = tid; k < n_perm; k += nt) perm[(int64_t)g * n_perm + k] = k;
+      if (tid == 0) status[g] = 0;
+    }
+    return;
+  }
+  const FusedBigLds L = fused_big_lds_layout(R);
+  const int R2 = R * R, PS = L.PS, XS = L.XS, TS = L.TS, MB = L.MB;
+  float *Pp = lds;                 // Pp[a*PS + b] = P[a,b], 0 for a == b and for b >= R
+  float *Xs = lds + L.off_XM;      // Xs[j*XS + b] = X[j,b], 0 for b >= R          (phase 1)
+  float *M = Xs;                   // M[j*R + a]                                    (phase 2)
+  float *T = Xs;                   // T[l*TS + k] = Xn[8k + l], l = 0..7            (phase 3)
+  uint8_t *Ab = reinterpret_cast<uint8_t *>(lds + L.off_mask);    // byte masks, rows of MB bytes
+  const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
+  float *Xg = X + g * strideX;
+
+  for (int e = tid; e < R * PS; e += nt) {
+    const int r = e / PS, c = e - r * PS;
+    Pp[e] = (c < R && c != r) ? Pg[(int64_t)r * ld + c] : 0.0f;
+  }
+  for (int e = tid; e < R * XS; e += nt) {
+    const int r = e / XS, c = e - r * XS;
+    Xs[e] = (c < R) ? Xg[(int64_t)r * ldx + c] : 0.0f;
+  }
+  for (int e = tid; e < R * MB; e += nt) {
+    const int r = e / MB, c = e - r * MB;
+    Ab[e] = (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) ? 1 : 0;
+  }
+  if (tid < 32) red[tid] = 0.f;
+  // element ownership as in mpm_fused_kernel: lane (ta, tj) owns column ta and rows tj + k*TJ
+  const int TJ = nt / R;
+  const int C = (R >= 8) ? (R & ~31) : (R & ~3);
+  const int nA = C * TJ, nB = (R - C) * TJ;
+  const int startB = (((nA + 63) & ~63) + nB <= nt) ? ((nA + 63) & ~63) : nA;
+  bool owner = false;
+  int ta = 0, tj = 0;
+  if (tid < nA) {
+    owner = true;
+    tj = tid / C;
+    ta = tid - tj * C;
+  } else if (tid >= startB && tid < startB + nB) {
+    owner = true;
+    const int u = tid - startB;
+    tj = u / (R - C);
+    ta = C + (u - tj * (R - C));
+  }
+  __syncthreads();
+
+  const int n8 = R2 & ~7;
+  const int JQ = (R + 3) >> 2;          // groups of 4 consecutive rows j
+  const int R4 = XS;
+  const int n_items = R * JQ;           // <= kBigItems * nt for R <= 128
+  int done = resume != nullptr ? iters_done[g] : 0;
+  int par = 0;
+  const int tid0 = tid, ta0 = ta, tj0 = tj;
+  for (int it = done; it < iters; ++it) {
+    // (the lane's coordinates pass through an opaque move once per iteration: the addresses of its
+    // sixteen rows are then recomputed where they are used, a few integer operations each, instead
+    // of being kept in registers across the whole loop, which made the kernel spill)
+    int tid = tid0, ta = ta0, tj = tj0;
+    asm volatile("" : "+v"(tid), "+v"(ta), "+v"(tj));
+    // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b], four rows j and one column a per item, the
+    // results held in registers until X is no longer read
+    float mreg[kBigItems][4];
+#pragma unroll
+    for (int q = 0; q < kBigItems; ++q) {
+      const int w = tid + q * nt;
+      mreg[q][0] = mreg[q][1] = mreg[q][2] = mreg[q][3] = 0.f;
+      if (w < n_items) {
+        const int jq = w / R, a = w - jq * R;
+        const int j0 = jq * 4;
+        const float *pr = Pp + a * PS;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        const float *x0 = Xs + j0 * XS;
+        const float *x1 = Xs + min(j0 + 1, R - 1) * XS;
+        const float *x2 = Xs + min(j0 + 2, R - 1) * XS;
+        const float *x3 = Xs + min(j0 + 3, R - 1) * XS;
+#pragma unroll 2
+        for (int b = 0; b < R4; b += 4) {
+          const f32x4_t p = *reinterpret_cast<const f32x4_t *>(pr + b);
+          const f32x4_t a0 = *reinterpret_cast<const f32x4_t *>(x0 + b);
+          const f32x4_t a1 = *reinterpret_cast<const f32x4_t *>(x1 + b);
+          const f32x4_t a2 = *reinterpret_cast<const f32x4_t *>(x2 + b);
+          const f32x4_t a3 = *reinterpret_cast<const f32x4_t *>(x3 + b);
+          f32x2_t t;
+          t = p.lo * a0.lo, m0 = fmaxf(fmaxf(m0, t.x), t.y);
+          t = p.hi * a0.hi, m0 = fmaxf(fmaxf(m0, t.x), t.y);
+          t = p.lo * a1.lo, m1 = fmaxf(fmaxf(m1, t.x), t.y);
+          t = p.hi * a1.hi, m1 = fmaxf(fmaxf(m1, t.x), t.y);
+          t = p.lo * a2.lo, m2 = fmaxf(fmaxf(m2, t.x), t.y);
+          t = p.hi * a2.hi, m2 = fmaxf(fmaxf(m2, t.x), t.y);
+          t = p.lo * a3.lo, m3 = fmaxf(fmaxf(m3, t.x), t.y);
+          t = p.hi * a3.hi, m3 = fmaxf(fmaxf(m3, t.x), t.y);
+        }
+        mreg[q][0] = m0, mreg[q][1] = m1, mreg[q][2] = m2, mreg[q][3] = m3;
+      }
+    }
+    __syncthreads();               // X has been read by everyone: M takes its place
+#pragma unroll
+    for (int q = 0; q < kBigItems; ++q) {
+      const int w = tid + q * nt;
+      if (w < n_items) {
+        const int jq = w / R, a = w - jq * R;
+        const int j0 = jq * 4;
+        M[j0 * R + a] = mreg[q][0];
+        if (j0 + 1 < R) M[(j0 + 1) * R + a] = mreg[q][1];
+        if (j0 + 2 < R) M[(j0 + 2) * R + a] = mreg[q][2];
+        if (j0 + 3 < R) M[(j0 + 3) * R + a] = mreg[q][3];
+      }
+    }
+    __syncthreads();
+    // phase 2: Xn[i,a] = X[i,a]*NS[i,a] + sum_{j: A[i,j]} M[j,a]  (canonical column sums), four
+    // rows of a lane at a time, the results in registers
+    float xn[kBigRows];
+#pragma unroll
+    for (int k = 0; k < kBigRows; ++k) xn[k] = 0.f;
+    if (owner) {
+      const float *Mcol = M + ta;
+      const bool casc = ta < C;
+#pragma unroll
+      for (int k0 = 0; k0 < kBigRows; k0 += 4) {
+        if (tj + k0 * TJ < R) {
+          float xv[4], nv[4], et[4];
+          const uint8_t *br[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = min(tj + (k0 + c) * TJ, R - 1);
+            br[c] = Ab + i * MB;
+            xv[c] = Xg[(int64_t)i * ldx + ta];
+            nv[c] = NSg[(int64_t)i * ld + ta];
+          }
+          if (casc)
+            cascade_chains_b<4>(Mcol, R, br, et);
+          else
+            ilp4_chains_b<4>(Mcol, R, br, et);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xn[k0 + c] = xv[c] * nv[c] + et[c];
+        }
+      }
+    }
+    __syncthreads();               // M has been read by everyone: the new X takes its place
+#pragma unroll
+    for (int k = 0; k < kBigRows; ++k) {
+      const int i = tj + k * TJ;
+      if (owner && i < R) {
+        const int e = i * R + ta;
+        if (e < n8)
+          T[(e & 7) * TS + (e >> 3)] = xn[k];
+        else
+          Ttail[e - n8] = xn[k];
+      }
+    }
+    __syncthreads();
+    // phase 3: canonical norm over the R*R elements in flat order
+    if (tid < 64) {
+      float acc = 0.f;
+      if (tid < 8) acc = norm_chain_rows(T + tid * TS, n8 >> 3);
+      const float nrm = norm_finish(acc, Ttail, R2 - n8);
+      if (tid == 0) s_nrm = nrm;
+    }
+    __syncthreads();
+    const float nrm = s_nrm;
+    float dmax = 0.f;
+    bool isnan_any = false;
+#pragma unroll
+    for (int k = 0; k < kBigRows; ++k) {
+      const int i = tj + k * TJ;
+      if (owner && i < R) {
+        const float v = xn[k] / nrm;
+        const float prev = Xg[(int64_t)i * ldx + ta];
+        Xg[(int64_t)i * ldx + ta] = v;
+        const float d = fabsf(v - prev);
+        isnan_any |= (d != d);
+        dmax = fmaxf(dmax, d);
+        Xs[i * XS + ta] = v;
+      }
+    }
+    if (isnan_any) dmax = INFINITY;
+    dmax = wave_max(dmax);
+    if ((tid & 63) == 0) red[par * 16 + (tid >> 6)] = dmax;
+    __syncthreads();
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < (kBigNT >> 6); q += 4) {
+      const f32x4_t r4 = *reinterpret_cast<const f32x4_t *>(red + par * 16 + q);
+      d = fmaxf(fmaxf(d, fmaxf(r4.x, r4.y)), fmaxf(r4.z, r4.w));
+    }
+    par ^= 1;
+    ++done;
+    if (early_stop && d < tol) break;
+  }
+  if (tid == 0) iters_done[g] = done;
+  if (perm != nullptr) {
+    __syncthreads();               // the last iteration's Xs (no iteration: the initial X)
+    if (tid < 64) lsap_wave(Xs, R, XS, tid, perm + (int64_t)g * n_perm, n_perm, status + g);
+  }
+}
+
 // after the persistent kernel: a queue fault (a bounded spin ran out) turns every graph's
 // iteration count into -(fault code), so that the caller can see that X is not to be trusted
 __global__ void mpm_queue_check_kernel(MpmQueue q, int n_graphs, int32_t *__restrict__ iters_done) {
@@ -2134,7 +2382,9 @@ static int64_t g_handoff_bytes = 256LL << 20;
 // control words + the layout of fused_lds_layout for the largest graph of the launch's size class
 constexpr int kFusedByteMaskMaxNodes = 88;      // classes served by the KMAX <= 8 kernel shapes
 static inline size_t mpm_fused_lds_bytes(int r_max) {
-  return sizeof(float) * (size_t)(kFusedCtl + fused_lds_layout(r_max, r_max <= kFusedByteMaskMaxNodes).total);
+  if (r_max > kFusedByteMaskMaxNodes)
+    return sizeof(float) * (size_t)(kFusedCtl + fused_big_lds_layout(r_max).total);
+  return sizeof(float) * (size_t)(kFusedCtl + fused_lds_layout(r_max, true).total);
 }
 constexpr size_t kMaxFusedLds = kMaxDynLds;
 
@@ -2589,7 +2839,7 @@ static int mpm_fused_launch(const float *d_A, const float *d_P, const float *d_N
     if (rm <= 44) return launch(mpm_fused_kernel<512, 4>, 512);
     if (rm <= 64) return launch(mpm_fused_kernel<1024, 4>, 1024);
     if (rm <= kFusedByteMaskMaxNodes) return launch(mpm_fused_kernel<1024, 8>, 1024);
-    return launch(mpm_fused_kernel<1024, 16>, 1024);
+    return launch(mpm_fused_big_kernel, kBigNT);
   };
   // Resumed graphs (the tail of the streamed matching; at most kFusedByteMaskMaxNodes nodes) all
   // run in ONE launch, in the kernel shape of the largest: the tail takes as long as its slowest

@@ -263,9 +263,9 @@ def mpm_pool_bwd(S, X, gY, gS=None) -> torch.Tensor:
 
 
 def mpm_fused_supported(r_max: int) -> bool:
-    """Whether the single-work-group fused MPM fits its LDS budget for this size."""
-    return r_max <= MAX_NODES_LDS and (128 + 12 * r_max * r_max + 16 * r_max
-                                       + 4 * r_max * ((r_max + 31) // 32)) <= 159 * 1024
+    """Whether the S-free MPM (one work-group per graph, the graph resident in LDS) takes graphs
+    of this size: up to GVAE_MAX_NODES_LDS nodes."""
+    return 0 < r_max <= MAX_NODES_LDS
 
 
 def mpm_fused(A, P, NS, R, r_max: int, X, iters: int = 50, tol: float = 1e-4,

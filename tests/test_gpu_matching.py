@@ -184,6 +184,35 @@ def test_fused_assign_large_and_invalid_graphs(hip):
     assert sorted(perm[1].cpu().tolist()) == list(range(64))
 
 
+def test_fused_supports_every_size_up_to_128(hip):
+    assert hip.mpm_fused_supported(128) and hip.mpm_fused_supported(116) and not hip.mpm_fused_supported(129)
+
+
+@pytest.mark.parametrize("sizes,N,cfg", [((116, 120, 126, 127, 128), 128, (6, 1e-4, True)),
+                                         ((89, 96, 97, 113, 128, 7, 30, 64), 128, (5, 1e-4, False)),
+                                         ((126,) + (31, 12, 44, 57, 2, 23, 38, 19, 70), 126, (50, 1e-4, True))])
+def test_sfree_mpm_above_115_nodes(hip, sizes, N, cfg):
+    """Launches whose largest graph has 89..128 nodes (the row maxima take X's place in LDS), with
+    smaller graphs beside it: stream == fused == oracle, bit for bit, and the same permutations.
+    The last case is one 126-node graph in an ENZYMES-shaped batch with the reference's defaults."""
+    rng = np.random.default_rng(sum(sizes))
+    As, Ps = [], []
+    for R in sizes:
+        up = np.triu((rng.random((R, R)) < min(0.9, 3.8 / max(1, R - 1) + 0.02)).astype(np.float32), 1)
+        As.append(up + up.T + np.eye(R, dtype=np.float32))
+        lg = np.triu(rng.normal(0, 1.5, (R, R)).astype(np.float32), 1)
+        Ps.append((1 / (1 + np.exp(-(lg + lg.T)))).astype(np.float32))
+    o = _run_all(hip, As, Ps, cfg, N=N, check_stream=True)
+    assert (o["status"] == 0).all()
+    for k, (A, P) in enumerate(zip(As, Ps)):
+        R = A.shape[0]
+        X, done = ora.mpm_sfree(A, P, iters=cfg[0], tol=cfg[1], early_stop=cfg[2])
+        assert o["done_fused"][k] == done == o["done_stream"][k], (R, o["done_fused"][k], done)
+        assert np.array_equal(o["X_fused"][k, :R, :R], X), R
+        assert np.array_equal(o["X_stream"][k, :R, :R], X), R
+        assert np.array_equal(o["perm"][k, :R], ora.assign_perm(X)), R
+
+
 def test_fused_assign_beyond_resident_capacity(hip):
     """More graphs than work-groups fit on the device at once: the call switches to two
     launches; X, iteration counts, permutations and status must not change."""
