@@ -1364,130 +1364,17 @@ __global__ __launch_bounds__(256) void mpm_second_norm_kernel(
 #define STAMP(k) do {} while (0)
 #endif
 
-// canonical column sums of NCH rows that share one column a: chain c adds, for j = 0..R-1 in
-// the canonical order, M[j,a] if bit j of mask row c is set and an exact +0 otherwise.  The
-// M values are loaded once per j (not once per chain) and the NCH chains are independent, so
-// the LDS latency and the add latency overlap.
-template <int NCH>
-__device__ __forceinline__ void cascade_chains(const float *__restrict__ Mcol, int R,
-                                               const uint32_t *const (&bits)[NCH],
-                                               float (&out)[NCH]) {
-  float l0[NCH], l1[NCH], l2[NCH], l3[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) l0[c] = l1[c] = l2[c] = l3[c] = 0.f;
-  int i = 0;
-  while (i + 16 <= R) {
-    float v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = Mcol[(i + t) * R];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const uint32_t w = bits[c][i >> 5] >> (i & 31);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) l0[c] += ((w >> t) & 1u) ? v[t] : 0.0f;
-    }
-    i += 16;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      l1[c] += l0[c];
-      l0[c] = 0.f;
-    }
-    if ((i & 0xF0) == 0) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        l2[c] += l1[c];
-        l1[c] = 0.f;
-      }
-      if ((i & 0xF00) == 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          l3[c] += l2[c];
-          l2[c] = 0.f;
-        }
-      }
-    }
-  }
-  for (; i < R; ++i) {
-    const float v = Mcol[i * R];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) l0[c] += ((bits[c][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    l0[c] += l1[c];
-    l0[c] += l2[c];
-    l0[c] += l3[c];
-    out[c] = l0[c];
-  }
-}
-
-// The same for columns that the canonical order sums as four interleaved strands (ilp4_sum):
-// strand s takes the terms j = 4t + s of the first 4*floor(R/4) rows, cascading after every 16
-// of ITS terms, i.e. after every 64 consecutive j; the remaining rows go to strand 0 after the
-// strands' levels are folded; then strand 0 receives strands 1, 2, 3.  Walking j upwards visits
-// the strands round-robin, so one pass over the column feeds all 4*NCH accumulators.  Valid for
-// R < 1024 (a strand never reaches its second cascade level).
-template <int NCH>
-__device__ __forceinline__ void ilp4_chains(const float *__restrict__ Mcol, int R,
-                                            const uint32_t *const (&bits)[NCH],
-                                            float (&out)[NCH]) {
-  float l0[NCH][4], l1[NCH][4];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) l0[c][q] = l1[c][q] = 0.f;
-  const int n44 = (R >> 2) << 2;
-  int i = 0;
-  for (; i + 16 <= n44; i += 16) {
-    float v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = Mcol[(i + t) * R];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const uint32_t w = bits[c][i >> 5] >> (i & 31);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) l0[c][t & 3] += ((w >> t) & 1u) ? v[t] : 0.0f;
-    }
-    if (((i + 16) & 63) == 0) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          l1[c][q] += l0[c][q];
-          l0[c][q] = 0.f;
-        }
-    }
-  }
-  for (; i < n44; i += 4) {
-    float v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = Mcol[(i + t) * R];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const uint32_t w = bits[c][i >> 5] >> (i & 31);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) l0[c][t] += ((w >> t) & 1u) ? v[t] : 0.0f;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) l0[c][q] += l1[c][q];   // the higher levels are +0: adding them changes nothing
-  for (; i < R; ++i) {
-    const float v = Mcol[i * R];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) l0[c][0] += ((bits[c][i >> 5] >> (i & 31)) & 1u) ? v : 0.0f;
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    l0[c][0] += l0[c][1];
-    l0[c][0] += l0[c][2];
-    l0[c][0] += l0[c][3];
-    out[c] = l0[c][0];
-  }
-}
-
-// The column sums with byte masks (one byte per (i, j): 1 when j is a neighbour of i): a term is
+// Canonical column sums of NCH rows that share one column a: chain c adds, for j = 0..R-1 in the
+// canonical order, M[j,a] if j is a neighbour of row c and an exact +0 otherwise.  The M values
+// are loaded once per j (not once per chain) and the chains are independent, so the LDS latency
+// and the add latency overlap.  Columns that the canonical order sums as four interleaved strands
+// (ilp4_sum): strand s takes the terms j = 4t + s of the first 4*floor(R/4) rows, cascading after
+// every 16 of ITS terms, i.e. after every 64 consecutive j; the remaining rows go to strand 0
+// after the strands' levels are folded; then strand 0 receives strands 1, 2, 3.  Walking j
+// upwards visits the strands round-robin, so one pass over the column feeds all 4*NCH
+// accumulators.  Valid for R < 1024 (a strand never reaches its second cascade level).
+//
+// The neighbours come as byte masks (one byte per (i, j): 1 when j is a neighbour of i): a term is
 // fma(M[j,a], mask, acc) -- M * 1 + acc rounds once, exactly as the sum does, and M * 0 + acc
 // leaves acc as it is -- so a pair of chains advances with one packed fma; the sixteen masks of
 // a chain and a block come with one 16-byte read.  mrow[c]: byte row of chain c, 16-byte aligned.
@@ -1676,7 +1563,7 @@ struct FusedLds {
   int PS, XS, TS, MB;     // row strides of P and X; lane stride of the norm layout; mask row bytes
   int off_X, off_M, off_mask, total;
 };
-__host__ __device__ inline FusedLds fused_lds_layout(int R, bool byte_masks) {
+__host__ __device__ inline FusedLds fused_lds_layout(int R) {
   FusedLds L;
   const int R4 = (R + 3) & ~3;
   L.PS = R4 + ((R4 & 7) == 4 ? 0 : 4);
@@ -1688,16 +1575,15 @@ __host__ __device__ inline FusedLds fused_lds_layout(int R, bool byte_masks) {
   L.off_M = L.off_X + R * L.XS;
   const int m = R * R > 8 * L.TS ? ((R * R + 3) & ~3) : 8 * L.TS;
   L.off_mask = L.off_M + m;
-  L.total = L.off_mask + (byte_masks ? R * L.MB / 4 : R * ((R + 31) >> 5));
+  L.total = L.off_mask + R * L.MB / 4;
   return L;
 }
 constexpr int kFusedCtl = 48;   // floats: [0,32) wavefront maxima (two sets), [32] norm, [36,44) norm tail
 
-// NT = work-group size, KMAX = rows per lane (ceil(R / floor(NT / R)) <= KMAX must hold).
-// KMAX <= 8: byte masks, node-similarity factor and previous X in registers.  KMAX = 16 (the
-// largest graphs, whose LDS has no room for byte masks and whose lanes have no registers to
-// spare): A as bit rows, the factor read from global memory at its use, the previous X kept in
-// the caller's X buffer and rewritten every iteration (both stay in L2).
+// NT = work-group size, KMAX = rows per lane (ceil(R / floor(NT / R)) <= KMAX <= 8 must hold).
+// The previous X stays in registers; so do the node-similarity factor and the unnormalised new
+// X up to KMAX = 4 (above, the factor is read from global memory at its use, where it stays in L2).
+// Graphs of more than 88 nodes: mpm_fused_big_kernel.
 template <int NT, int KMAX>
 __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const float *__restrict__ A, const float *__restrict__ P, const float *__restrict__ NS,
@@ -1720,7 +1606,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   float *lds = lds_all + kFusedCtl;
   const int g = blockIdx.x, tid = threadIdx.x;
   constexpr int nt = NT;
-  constexpr bool kRegs = KMAX <= 8;
+  static_assert(KMAX <= 8, "larger graphs: mpm_fused_big_kernel");
   constexpr int NCH = KMAX < 4 ? KMAX : 4;          // chains (rows) a lane advances together
   constexpr bool kXnRegs = KMAX <= 4;               // the unnormalised new X stays in registers
   constexpr int kChainUnroll = kXnRegs ? KMAX / NCH : 1;
@@ -1733,14 +1619,13 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     }
     return;
   }
-  const FusedLds L = fused_lds_layout(R, kRegs);
-  const int R2 = R * R, W = (R + 31) >> 5, PS = L.PS, XS = L.XS, TS = L.TS, MB = L.MB;
+  const FusedLds L = fused_lds_layout(R);
+  const int R2 = R * R, PS = L.PS, XS = L.XS, TS = L.TS, MB = L.MB;
   float *Pp = lds;                 // Pp[a*PS + b] = P[a,b], 0 for a == b and for b >= R
   float *Xs = lds + L.off_X;       // Xs[j*XS + b] = X[j,b], 0 for b >= R
   float *M = lds + L.off_M;        // M[j*R + a]; after the column sums the same words hold T
   float *T = M;                    // T[l*TS + k] = Xn[8k + l] (flat element order), l = 0..7
   uint8_t *Ab = reinterpret_cast<uint8_t *>(lds + L.off_mask);    // byte masks, rows of MB bytes
-  uint32_t *Abits = reinterpret_cast<uint32_t *>(lds + L.off_mask);  // or bit rows of W words
   const float *Ag = A + g * stride, *Pg = P + g * stride, *NSg = NS + g * stride;
   float *Xg = X + g * strideX;
 
@@ -1752,21 +1637,9 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     const int r = e / XS, c = e - r * XS;
     Xs[e] = (c < R) ? Xg[(int64_t)r * ldx + c] : 0.0f;
   }
-  if constexpr (kRegs) {
-    for (int e = tid; e < R * MB; e += nt) {
-      const int r = e / MB, c = e - r * MB;
-      Ab[e] = (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) ? 1 : 0;
-    }
-  } else {
-    for (int e = tid; e < R * W; e += nt) {
-      const int r = e / W, w = e - r * W;
-      uint32_t bits = 0;
-      for (int k = 0; k < 32; ++k) {
-        const int c = w * 32 + k;
-        if (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) bits |= (1u << k);
-      }
-      Abits[e] = bits;
-    }
+  for (int e = tid; e < R * MB; e += nt) {
+    const int r = e / MB, c = e - r * MB;
+    Ab[e] = (c < R && c != r && Ag[(int64_t)r * ld + c] != 0.0f) ? 1 : 0;
   }
   if (tid < 32) red[tid] = 0.f;
   // element ownership for the column sums and the update: lane (ta, tj) owns column a = ta and
@@ -1789,19 +1662,16 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     tj = u / (R - C);
     ta = C + (u - tj * (R - C));
   }
-  // registers per lane: previous X (KMAX <= 8); the unnormalised new X and the node-similarity
-  // factor (KMAX <= 4; otherwise the factor is read from global memory at its use, where it
-  // stays in L2)
+  // registers per lane: previous X; the unnormalised new X and the node-similarity factor
+  // (KMAX <= 4; otherwise the factor is read from global memory at its use, where it stays in L2)
   constexpr bool kNsRegs = KMAX <= 4;
-  constexpr int KR = kRegs ? KMAX : 1, KN = kNsRegs ? KMAX : 1, KX = kXnRegs ? KMAX : 1;
-  float nsv[KN], xprev[KR], xn[KX];
-  if constexpr (kRegs) {
+  constexpr int KN = kNsRegs ? KMAX : 1, KX = kXnRegs ? KMAX : 1;
+  float nsv[KN], xprev[KMAX], xn[KX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const int i = tj + k * TJ;
-      if constexpr (kNsRegs) nsv[k] = (owner && i < R) ? NSg[(int64_t)i * ld + ta] : 0.f;
-      xprev[k] = (owner && i < R) ? Xg[(int64_t)i * ldx + ta] : 0.f;
-    }
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = tj + k * TJ;
+    if constexpr (kNsRegs) nsv[k] = (owner && i < R) ? NSg[(int64_t)i * ld + ta] : 0.f;
+    xprev[k] = (owner && i < R) ? Xg[(int64_t)i * ldx + ta] : 0.f;
   }
   auto ns_of = [&](int k, int i) { return kNsRegs ? nsv[kNsRegs ? k : 0] : NSg[(int64_t)i * ld + ta]; };
   __syncthreads();
@@ -1888,23 +1758,13 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       for (int k0 = 0; k0 < KMAX; k0 += NCH) {
         if (tj + k0 * TJ < R) {
           float et[NCH];
-          if constexpr (kRegs) {
-            const uint8_t *br[NCH];
+          const uint8_t *br[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) br[c] = Ab + min(tj + (k0 + c) * TJ, R - 1) * MB;
-            if (casc)
-              cascade_chains_b<NCH>(Mcol, R, br, et);
-            else
-              ilp4_chains_b<NCH>(Mcol, R, br, et);
-          } else {
-            const uint32_t *br[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) br[c] = Abits + min(tj + (k0 + c) * TJ, R - 1) * W;
-            if (casc)
-              cascade_chains<NCH>(Mcol, R, br, et);
-            else
-              ilp4_chains<NCH>(Mcol, R, br, et);
-          }
+          for (int c = 0; c < NCH; ++c) br[c] = Ab + min(tj + (k0 + c) * TJ, R - 1) * MB;
+          if (casc)
+            cascade_chains_b<NCH>(Mcol, R, br, et);
+          else
+            ilp4_chains_b<NCH>(Mcol, R, br, et);
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int i = tj + (k0 + c) * TJ;
@@ -1951,14 +1811,8 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       const int i = tj + k * TJ;
       if (owner && i < R) {
         const float v = (kXnRegs ? xn[kXnRegs ? k : 0] : Xs[i * XS + ta]) / nrm;
-        float prev;
-        if constexpr (kRegs) {
-          prev = xprev[k];
-          xprev[k] = v;
-        } else {
-          prev = Xg[(int64_t)i * ldx + ta];
-          Xg[(int64_t)i * ldx + ta] = v;
-        }
+        const float prev = xprev[k];
+        xprev[k] = v;
         const float d = fabsf(v - prev);
         isnan_any |= (d != d);
         dmax = fmaxf(dmax, d);
@@ -1987,12 +1841,10 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
     printf("fused stamps R=%d iters=%d: maxprod %lld (lane 0 without the barrier %lld)  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
            R, done, st_acc[0], st_inner, st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
 #endif
-  if constexpr (kRegs) {
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const int i = tj + k * TJ;
-      if (owner && i < R) Xg[(int64_t)i * ldx + ta] = xprev[k];
-    }
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = tj + k * TJ;
+    if (owner && i < R) Xg[(int64_t)i * ldx + ta] = xprev[k];
   }
   if (tid == 0) iters_done[g] = done;
   // Epilogue (perm != nullptr): the assignment of this graph, by the first wavefront, straight
@@ -2384,7 +2236,7 @@ constexpr int kFusedByteMaskMaxNodes = 88;      // classes served by the KMAX <=
 static inline size_t mpm_fused_lds_bytes(int r_max) {
   if (r_max > kFusedByteMaskMaxNodes)
     return sizeof(float) * (size_t)(kFusedCtl + fused_big_lds_layout(r_max).total);
-  return sizeof(float) * (size_t)(kFusedCtl + fused_lds_layout(r_max, true).total);
+  return sizeof(float) * (size_t)(kFusedCtl + fused_lds_layout(r_max).total);
 }
 constexpr size_t kMaxFusedLds = kMaxDynLds;
 
