@@ -557,7 +557,8 @@ struct MpmQueue {
   // finishes an iteration in that state leaves the queue with handoff[g] = 1, and the S-free
   // kernel (same recurrence, same bits, no HBM traffic in its loop) runs its remaining
   // iterations after this launch.
-  int32_t *handoff;           // [n_graphs] out
+  int32_t *handoff;           // [n_graphs] out (nullptr: no hand-off in this launch)
+  int32_t *handoff_flags;     // the same words, always: cleared by every launch's set-up
   const int32_t *sfree_ok;    // [n_graphs] bit 1: the S-free form is valid for the graph
   int handoff_kb, handoff_rmax;
   unsigned long long *stats;  // [0] bytes streamed (4R^4 + 12R^2 per executed graph-iteration)  [1] graph-iterations
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     live += n > 0;
     if (n > 0) kb += mpm_slab_kb(Rarr[g], s_row_stride(Rarr[g], layout));
     q.arrive[g] = 0;
-    if (q.handoff) q.handoff[g] = 0;
+    q.handoff_flags[g] = 0;   // whether or not this launch hands graphs over: the tail reads them
     if (!first_stop) iters_done[g] = 0;
   }
   s_part[tid] = mine;
@@ -2228,7 +2229,7 @@ int64_t gvae_mpm_stream_ws_bytes(int n_graphs, int ldx) {
 // 128 / 192 / 256 MiB: 3.27 / 3.14 / 3.00 ms and 3.09 / 2.88 / 2.72 ms (58.9 / 59.5 / 59.1 %).
 static int64_t g_handoff_bytes = 256LL << 20;
 #ifndef GVAE_HANDOFF_MAX_NODES
-#define GVAE_HANDOFF_MAX_NODES 88
+#define GVAE_HANDOFF_MAX_NODES GVAE_MAX_NODES_LDS
 #endif
 
 // control words + the layout of fused_lds_layout for the largest graph of the launch's size class
@@ -2284,6 +2285,7 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // the S-free kernel takes over the latency-bound tail (callers that hold A and P only)
   const bool handoff = handoff_rmax > 0 && first_iter_done && early_stop && g_handoff_bytes > 0;
   q.handoff = handoff ? m.handoff : nullptr;
+  q.handoff_flags = m.handoff;
   q.sfree_ok = m.stop;
   q.handoff_rmax = handoff_rmax;
   q.handoff_kb = (int)(g_handoff_bytes >> 10 > INT32_MAX ? INT32_MAX : g_handoff_bytes >> 10);
@@ -2494,6 +2496,7 @@ int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layou
                            early_stop, d_iters_done, ws, false, stream, /*profiled=*/false);
 }
 
+// (read when a streaming launch is enqueued; launches already enqueued keep the value they saw)
 int gvae_set_stream_handoff_bytes(int64_t bytes) {
   GVAE_REQUIRE(bytes >= 0, GVAE_EINVAL, "set_stream_handoff_bytes: negative threshold");
   g_handoff_bytes = bytes;
@@ -2527,8 +2530,11 @@ int gvae::match_stream_tail(const float *d_A, const float *d_P, const float *d_N
                             int n_graphs, int ld, int64_t stride, int r_max, float *d_X, int ldx,
                             int64_t strideX, int iters, float tol, int early_stop,
                             int32_t *d_iters_done, void *d_ws, void *stream) {
-  // (the same conditions under which match_stream_iterate lets its launch set the flags)
-  if (!early_stop || iters <= 1 || n_graphs <= 0 || g_handoff_bytes <= 0) return GVAE_OK;
+  // (without early stop or with a single iteration there is no streaming launch behind this call;
+  // otherwise the flags are whatever that launch wrote -- its set-up clears them, its hand-off
+  // decision is taken when it is enqueued -- so a change of the threshold between the launch and
+  // this call cannot strand a graph)
+  if (!early_stop || iters <= 1 || n_graphs <= 0) return GVAE_OK;
   GVAE_REQUIRE(d_A && d_P && d_NS && d_R && d_X && d_iters_done && d_ws, GVAE_EINVAL,
                "match_stream (tail): null pointer");
   const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
@@ -2610,7 +2616,7 @@ int gvae::match_stream_prep(const float *d_A, const float *d_P, const float *d_N
 }
 
 // Iterations 2..k of the graphs match_stream_prep left unconverged, by the persistent streaming
-// launch; with early stop it hands the latency-bound tail of graphs of at most 88 nodes to
+// launch; with early stop it hands the latency-bound tail of graphs the S-free kernel takes to
 // match_stream_tail (flags in the workspace).
 int gvae::match_stream_iterate(const int32_t *d_R, int n_graphs, int r_max, int s_layout,
                                const float *d_S, const int64_t *d_S_off, float *d_X, int ldx,
@@ -2623,9 +2629,9 @@ int gvae::match_stream_iterate(const int32_t *d_R, int n_graphs, int r_max, int 
   // Graphs small enough for the S-free kernel may be handed to it once the batch is bound by
   // the latency of an iteration rather than by HBM (see MpmQueue): same X, same iteration
   // counts, bit for bit, whichever kernel runs an iteration.
-  // Only graphs of at most 88 nodes (the size classes of the S-free kernel that keep byte masks):
-  // there an S-free iteration takes 5 us (32 nodes) to 34 us (88), less than the chain of one
-  // streamed iteration of a graph that has the device to itself (19 us + its slab's transfer).
+  // Every size the S-free kernel takes: an S-free iteration costs 5 us (32 nodes), 34 us (88) or
+  // 78 us (128), less than the chain of one streamed iteration of a graph that has the device to
+  // itself (19 us + its slab's transfer: 64 MiB - 1 GiB at a quarter of the streaming rate).
   const int r_cap = r_max < GVAE_HANDOFF_MAX_NODES ? r_max : GVAE_HANDOFF_MAX_NODES;
   const bool handoff = early_stop && g_handoff_bytes > 0 && r_cap > 0;
   return mpm_stream_launch(d_S, d_S_off, s_layout, d_R, n_graphs, r_max, d_X, ldx, strideX, iters, tol,

@@ -471,7 +471,7 @@ def test_match_stream_tail_handoff(hip):
     form exists) is never handed off; the workspace counters say what the streaming kernel ran."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(23)
-    sizes = (32, 31, 17, 40, 9, 64, 33, 2, 25, 48, 12, 70, 88, 89, 96)
+    sizes = (32, 31, 17, 40, 9, 64, 33, 2, 25, 48, 12, 70, 88, 89, 96, 116, 128)
     As, Ps = [], []
     for k, R in enumerate(sizes):
         w = (rng.random((R, R)) < 0.35).astype(np.float32)
@@ -509,9 +509,9 @@ def test_match_stream_tail_handoff(hip):
         # or at least 89 nodes from the kernel that writes the tensor; the rest was streamed ...
         rest = it - np.minimum(it, np.where((r <= 64) | (r >= 89), 2, 1))
         assert streamed["off"] == (int((per_gi * rest).sum()), int(rest.sum()))
-        # ... or, handed off at once, one streamed iteration per graph of at most 88 nodes that
-        # needed one (larger graphs and the weighted graph are never handed off)
-        keep = (np.arange(len(Rh)) == 4) | (r > 88)
+        # ... or, handed off at once, one streamed iteration per graph that needed one (the
+        # weighted graph is never handed off)
+        keep = np.arange(len(Rh)) == 4
         one = np.where(keep, rest, np.minimum(rest, 1))
         assert streamed["always"] == (int((per_gi * one).sum()), int(one.sum()))
         assert streamed["always"][1] <= streamed["default"][1] <= streamed["off"][1]
