@@ -94,7 +94,12 @@ class _MpmFunction(torch.autograd.Function):
     """Autograd of `_mpm`.  Forward: the streamed kernel.  Backward: the trajectory is recomputed
     one iteration per launch (same kernel, hence the same bits), then walked backwards; every
     step differentiates the normalisation and replays the maxima of the pooling
-    (gvae_mpm_pool_bwd)."""
+    (gvae_mpm_pool_bwd).  Limits: one graph of at most 255 nodes with a dense (R,R,R,R) gradient
+    w.r.t. S; every X_t of the trajectory is kept.  The pooling backward adds the shares of
+    X[j,b] with float atomics, so the gradient (unlike every forward result of the library) is
+    not bit-reproducible from run to run; the reference pins only that it is finite
+    (model_legacy2.py:670-684).  Not on the training path: the step never differentiates the
+    matching (model.py:319 detaches X)."""
 
     @staticmethod
     def forward(ctx, X0, S, iters, tol, early_stop, dev):

@@ -154,14 +154,18 @@ class HostStagedCollectives:
         return not t.is_cuda or dist.get_backend(self.group) == "nccl"
 
     def _staged(self, t: torch.Tensor, fn) -> None:
+        """`t` must be contiguous (the result is written back through a flat view of it) and all
+        calls must come from one stream: the pinned buffer of a (size, dtype) is reused."""
+        if not t.is_contiguous():
+            raise ValueError("HostStagedCollectives: the tensor must be contiguous")
         key = (t.numel(), t.dtype)
         h = self._pinned.get(key)
         if h is None:
             h = self._pinned[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
-        h.copy_(t.reshape(-1), non_blocking=True)
+        h.copy_(t.view(-1), non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
         fn(h)
-        t.reshape(-1).copy_(h, non_blocking=True)
+        t.view(-1).copy_(h, non_blocking=True)
 
     def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
         if self._direct(t):
@@ -292,6 +296,12 @@ class TrainStep:
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)
+        # the [rec, kl, max_logit, logvar_max] copies a step returns: a ring allocated once, so that
+        # no block of the caching allocator changes hands between streams on the way (a copy is
+        # written on a side stream; a block allocated per step on the main stream could still be
+        # in use by earlier main-stream work when that write lands)
+        self._out_ring = torch.zeros(32, 4, dtype=torch.float32, device=flat.device)
+        self._out_next = 0
         self.grads = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
@@ -333,8 +343,9 @@ class TrainStep:
 
     def __call__(self, batch: DenseGraphBatch, beta: float, lr_scale: float,
                  eps: torch.Tensor | None = None) -> torch.Tensor:
-        """One optimisation step; returns a copy of [rec, kl, max_logit, logvar_max] (device).
-        `eps` (B, z_dim) overrides the reparameterisation noise (tests)."""
+        """One optimisation step; returns a copy of [rec, kl, max_logit, logvar_max] (device; with
+        the matching on a side stream it is a row of a ring of 32 buffers, overwritten 32 steps
+        later).  `eps` (B, z_dim) overrides the reparameterisation noise (tests)."""
         model = self.model
         if self.collectives and self.sync_bn_buffers:
             # DDP's broadcast_buffers: every forward starts from rank 0's running statistics
@@ -409,8 +420,8 @@ class TrainStep:
                     self._ev_tail_last = self._ev_tail[k]
                     tail.wait_event(self._ev_tail[k])
                     res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
-                out = torch.empty_like(res)          # allocated on the current stream, written on `last`
-                out.record_stream(last)
+                out = self._out_ring[self._out_next]  # written on `last`; reused 32 steps later
+                self._out_next = (self._out_next + 1) % self._out_ring.shape[0]
                 if self._ev_acc_last is not None and self._acc_stream_last is not last:
                     last.wait_event(self._ev_acc_last)       # the loss sum is updated in step order
                 if hasattr(eng, "accumulate_loss"):

@@ -102,14 +102,19 @@ int gvae_mpm_pool_bwd(const float *d_S, int R, const float *d_X, const float *d_
                       float *d_gS, void *stream);
 
 /* gvae_mpm_stream without the workspace argument, for callers that cannot allocate device
- * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * memory (tight serving loops, harnesses that forbid hipMalloc).
  * No counterpart in the reference.  The workspace is a built-in device array of
  * GVAE_STATIC_SCRATCH_BYTES bytes per GPU (held from the first call on that GPU until the
  * process ends); the call allocates and frees nothing and records no profiler events.
  * Accepted sizes: gvae_mpm_stream_ws_bytes(n_graphs, ldx) <= GVAE_STATIC_SCRATCH_BYTES (e.g. 340
  * graphs at ldx 32, 100 at ldx 64, 28 at ldx 128); larger ones fail with GVAE_ELIMIT.  Every call
  * on a GPU shares that GPU's array: calls on one GPU must not overlap (two streams, two
- * threads), they would race on the queue.  Same X and iteration counts as gvae_mpm_stream. */
+ * threads), they would race on the queue.  Same X and iteration counts as gvae_mpm_stream.
+ * The first call on a GPU looks the array's address up (and, for r_max above 64 or so, raises the
+ * kernel's dynamic-LDS limit): host-side set-up that must not happen inside a stream capture, and
+ * the call has not been exercised under capture at all.  The first 16 bytes of the array are the
+ * kernel's statistics words (gvae_mpm_stream_stats); they start at zero with the process and
+ * only ever accumulate. */
 #define GVAE_STATIC_SCRATCH_BYTES (2 << 20)
 int gvae_mpm_stream_static(const float *d_S, const int64_t *d_S_off, int s_layout, const int32_t *d_R,
                            int n_graphs, int r_max, float *d_X, int ldx, int64_t strideX, int iters,
