@@ -123,33 +123,39 @@ def test_matching_on_reference_probabilities_large(golden_dir):
             assert np.array_equal(perm[g, :r].cpu().numpy(), G.perms[g])
 
 
-def _ragged_batch(N, sizes, seed):
+def _ragged_batch(N, sizes, seed, feat="deg"):
     from graphvae.data import collate, graph_from_adjacency
     rng = np.random.default_rng(seed)
     recs = []
     for r in sizes:
         p = min(1.0, 3.8 / max(r - 1, 1))
         up = np.triu(rng.random((r, r)) < p, 1)
-        recs.append(graph_from_adjacency((up | up.T).astype(np.float32), N, "deg"))
+        recs.append(graph_from_adjacency((up | up.T).astype(np.float32), N, feat))
     return collate(recs, N)
 
 
-@pytest.mark.parametrize("N,kind,B,matching", [
-    (64, "dense", 8, "fused"), (64, "dense", 8, "stream"),
-    (126, "ragged", 8, "auto"), (126, "ragged", 8, "stream"),
-    (128, "dense", 4, "stream")])
-def test_full_size_step_vs_cpu_restatement(N, kind, B, matching):
-    """Whole step at full graph sizes (dense R = max_nodes; ENZYMES-shaped up to 126 nodes)
-    against the CPU restatement (S-free C oracle for the MPM): losses, per-graph terms, every
-    gradient at 1e-5 (+ the restatement's own distance from float64), matching bit-exact."""
+@pytest.mark.parametrize("N,kind,B,matching,feat", [
+    (64, "dense", 8, "fused", "deg"), (64, "dense", 8, "stream", "deg"),
+    (126, "ragged", 8, "auto", "deg"), (126, "ragged", 8, "stream", "deg"), (126, "ragged", 8, "fused", "deg"),
+    (128, "dense", 4, "stream", "deg"), (128, "dense", 4, "auto", "deg"),
+    (64, "ragged", 8, "auto", "id"), (126, "ragged", 8, "auto", "id"), (128, "dense", 4, "fused", "id")])
+def test_full_size_step_vs_cpu_restatement(N, kind, B, matching, feat):
+    """Whole step at full graph sizes (dense R = max_nodes; ENZYMES-shaped up to 126 nodes, one
+    126-node graph among small ones) against the CPU restatement (S-free C oracle for the MPM):
+    losses, per-graph terms, every gradient at 1e-5 (+ the restatement's own distance from
+    float64), matching bit-exact -- under every matching path, and with `id` features
+    (in_dim = max_nodes = 64 / 126 / 128 input columns, rows of x only for the real nodes:
+    reference train_ddp.py:69-71)."""
     from graphvae.data import synthetic_batch
     from graphvae.models import GraphVAE
     if kind == "dense":
-        hb = synthetic_batch("dense", B, N, "deg", seed=21)
+        hb = synthetic_batch("dense", B, N, feat, seed=21)
     else:
-        hb = _ragged_batch(N, [126, 82, 33, 117, 2, 64, 101, 19][:B], seed=22)
+        hb = _ragged_batch(N, [min(N, r) for r in [126, 82, 33, 117, 2, 64, 101, 19][:B]], seed=22, feat=feat)
+    F_in = int(hb.x.shape[-1])
+    assert F_in == (1 if feat == "deg" else N)
     torch.manual_seed(17)
-    model = GraphVAE(1, 128, 64, N, matching=matching)
+    model = GraphVAE(F_in, 128, 64, N, matching=matching)
     with torch.no_grad():
         for n_, p in model.named_parameters():
             if n_.endswith("bias") or n_.startswith("bn"):
@@ -163,6 +169,9 @@ def test_full_size_step_vs_cpu_restatement(N, kind, B, matching):
     out = model.forward_with_eps(batch, eps.to(DEV))
     out["loss"].backward()
     _check_matching_bits(model, batch)
+    if matching == "auto":      # every size up to 128 nodes has an S-free kernel
+        from graphvae.engine import MATCH_FUSED
+        assert model._engine.last_mode == MATCH_FUSED
 
     st = R.make_trainable(state0)
     graphs = R.graphs_from_arrays(hb.x, hb.adj_dense, hb.n_x, hb.num_real_nodes)
