@@ -39,7 +39,7 @@ def enc64(g):
     Y2 = Ah @ (H1 @ st["conv2.lin.weight"].t())
     pre2 = Y2 + st["conv2.bias"]; m2 = pre2.mean(0); v2 = pre2.var(0, unbiased=False)
     H2 = torch.relu((pre2 - m2) / torch.sqrt(v2 + 1e-5) * st["bn2.weight"] + st["bn2.bias"])
-    return dict(Y1=Y1, H1=H1, Y2=Y2, H2=H2, gvec=H2.sum(0) / R, var1=v, var2=v2)
+    return dict(Y1=pre - m, H1=H1, Y2=pre2 - m2, H2=H2, gvec=H2.sum(0) / R, var1=v, var2=v2)   # Y: centred, as the workspace keeps it
 for name in ("Y1", "H1", "Y2", "H2", "gvec"):
     t = eng.debug_tensor(name, B).cpu().double()
     worst = 0

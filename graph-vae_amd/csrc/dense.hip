@@ -296,7 +296,7 @@ __device__ __forceinline__ double quad_rows_sum(double v, double (*sh)[64], int 
 }
 
 __device__ __forceinline__ void bn_relu_fwd_body(
-    const float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
+    float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ run_mean,
     const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
     float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
@@ -308,7 +308,7 @@ __device__ __forceinline__ void bn_relu_fwd_body(
   const int nx = n_x[g];
   // which statistics this forward normalised with: the backward of the batch reads it
   if (mode_o && g == 0 && slab == 0 && tid == 0) mode_o[0] = train;
-  const float *Yg = Y + (int64_t)g * N * H;
+  float *Yg = Y + (int64_t)g * N * H;
   float *Og = out + (int64_t)g * N * H;
   const float b = cv ? bias[c] : 0.0f;
   float mean, invstd;
@@ -341,17 +341,18 @@ __device__ __forceinline__ void bn_relu_fwd_body(
   if (!cv) return;
   const float ga = gamma[c], be = beta[c];
   for (int i = rl; i < N; i += 4) {
-    float o = 0.0f;
+    float o = 0.0f, xc = 0.0f;
     if (i < nx) {
-      const float xh = ((Yg[(int64_t)i * H + c] + b) - mean) * invstd;
-      o = fmaxf(xh * ga + be, 0.0f);
+      xc = (Yg[(int64_t)i * H + c] + b) - mean;
+      o = fmaxf(xc * invstd * ga + be, 0.0f);
     }
     Og[(int64_t)i * H + c] = o;
+    Yg[(int64_t)i * H + c] = xc;      // the backward reads the centred value
   }
 }
 
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
-    const float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
+    float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ run_mean,
     const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
     float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
                    var_unb_o, mode_o, blockIdx.y, blockIdx.x);
 }
 
-int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
+int launch_bn_relu_fwd(float *Y, const float *bias, const float *gamma, const float *beta,
                        const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
                        int H, int train, float *out, float *mean, float *invstd, float *var_unb,
                        int32_t *mode_out, hipStream_t s) {
@@ -405,7 +406,8 @@ int launch_bn_running_update(const BnRunningArgs &a, hipStream_t s) {
   return check_launch("bn_running_update");
 }
 
-// backward of relu(BN(Y + bias)) (sums in double):
+// backward of relu(BN(Y + bias)) (sums in double); the forward has left the CENTRED value
+// y - mean = Y + bias - mean in the Y buffer (bias and mean are not read again):
 //   dpre = dOut * (out > 0);  dbeta = sum dpre;  dot = sum dpre * (y - mean);  dgamma = dot * invstd
 //   batch statistics (training forward):
 //     dY = (dpre - dbeta/n - (y - mean) * dot * invstd^2 / n) * invstd * gamma
@@ -424,15 +426,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   const bool cv = c < H;
   const int nx = n_x[g];
   const int64_t base = (int64_t)g * N * H;
-  const float b = cv ? bias[c] : 0.0f;
-  const float mu = cv ? mean[(int64_t)g * H + c] : 0.0f;
   const float is = cv ? invstd[(int64_t)g * H + c] : 0.0f;
   double sb = 0.0, dot = 0.0;
   if (cv) for (int i = rl; i < nx; i += 4) {
     const int64_t e = base + (int64_t)i * H + c;
     const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
     sb += (double)dp;
-    dot += (double)dp * (double)((Y[e] + b) - mu);
+    dot += (double)dp * (double)Y[e];
   }
   sb = quad_rows_sum(sb, sh, rl, cl);
   dot = quad_rows_sum(dot, sh, rl, cl);
@@ -446,8 +446,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     float v = 0.0f;
     if (i < nx) {
       const float dp = out[e] > 0.0f ? dOut[e] : 0.0f;
-      const float xc = (Y[e] + b) - mu;
-      v = (dp - dmean - xc * k) * is * ga;
+      v = (dp - dmean - Y[e] * k) * is * ga;
     }
     dY[e] = v;
     sdy += (double)v;
@@ -615,20 +614,10 @@ int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, in
 // GCN layers (X W^T, Ahat * ., BatchNorm + ReLU), pooling, the two heads, reparameterisation and
 // the first decoder layers, as stages of ONE kernel separated by work-group barriers.  Everything
 // up to the pooled vector is local to a graph (BatchNorm runs over a graph's own rows), so the
-// chain needs no grid-wide step; the stages are the device functions of the stand-alone kernels
-// (same tiles, same summation orders), and the intermediate tensors go through the workspace in
-// global memory as before (the backward reads them), where a work-group finds its own writes
-// after a barrier.  16 launches of 4-12 us become one.
+// chain needs no grid-wide step.  Two kernels: model_fwd_lds_kernel (activations in LDS) and
+// model_fwd_graph_kernel (any size, activations through global memory); both leave the tensors
+// the backward reads in the workspace.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void gemm_stage(const GemmDesc &d, int z) {
-  const int ty = (d.M + GT_M - 1) / GT_M, tx = (d.N + GT_N - 1) / GT_N;
-  for (int by = 0; by < ty; ++by)
-    for (int bx = 0; bx < tx; ++bx) {
-      gemm_tile(d, bx, by, z);
-      __syncthreads();          // the tile's stores, and its LDS operands, before the next one
-    }
-}
-
 // out[n] = [relu](bias[n] + sum_k in[k] * W[n*K + k]) for one row, one lane per output
 // (`in` was written earlier in the same kernel: no __restrict__, it must be read with ordinary
 // vector loads after the barrier)
@@ -644,68 +633,18 @@ __device__ __forceinline__ void row_linear(const float *in, const float *__restr
   }
 }
 
-__global__ __launch_bounds__(256) void model_fwd_graph_kernel(ModelFwdArgs a) {
-  const int g = blockIdx.x;
-  const int N = a.N, F = a.F, H = a.H, Z = a.Z;
-  const int64_t NH = (int64_t)N * H;
-  gcn_norm_adj_body(a.adj, a.n_x, a.R, N, a.Ahat, g);
-  GemmDesc lin, agg;
-  // layer 1
-  lin.A = a.x + (int64_t)g * N * F; lin.a_rs = F; lin.a_cs = 1;
-  lin.B = a.W1; lin.b_rs = 1; lin.b_cs = F;
-  lin.C = a.H0a + g * NH; lin.c_rs = H; lin.M = N; lin.N = H; lin.K = F;
-  gemm_stage(lin, 0);
-  agg.A = a.Ahat; agg.a_rs = N; agg.a_cs = 1; agg.a_bs = (int64_t)N * N;
-  agg.B = a.H0a; agg.b_rs = H; agg.b_cs = 1; agg.b_bs = NH;
-  agg.C = a.Y1; agg.c_rs = H; agg.c_bs = NH; agg.M = N; agg.N = H; agg.K = N;
-  gemm_stage(agg, g);
-  for (int slab = 0; slab * 64 < H; ++slab) {
-    bn_relu_fwd_body(a.Y1, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.n_x, N, H, a.train, a.H1, a.mean1,
-                     a.invstd1, a.varu1, a.bn_mode, g, slab);
-    __syncthreads();
-  }
-  // layer 2
-  lin.A = a.H1 + g * NH; lin.a_rs = H; lin.B = a.W2; lin.b_cs = H; lin.C = a.H0b + g * NH; lin.K = H;
-  gemm_stage(lin, 0);
-  agg.B = a.H0b; agg.C = a.Y2;
-  gemm_stage(agg, g);
-  for (int slab = 0; slab * 64 < H; ++slab) {
-    bn_relu_fwd_body(a.Y2, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.n_x, N, H, a.train, a.H2, a.mean2,
-                     a.invstd2, a.varu2, nullptr, g, slab);
-    __syncthreads();
-  }
-  for (int slab = 0; slab * 64 < H; ++slab) {
-    pool_fwd_body(a.H2, a.n_x, a.R, N, H, a.gvec, g, slab);
-    __syncthreads();
-  }
-  // heads, reparameterisation, first decoder layers: one row per graph
-  const float *gv = a.gvec + (int64_t)g * H;
-  row_linear(gv, a.Wmu, a.bmu, a.mu + (int64_t)g * Z, Z, H, 0);
-  row_linear(gv, a.Wlv, a.blv, a.lvraw + (int64_t)g * Z, Z, H, 0);
-  __syncthreads();
-  for (int k = threadIdx.x; k < Z; k += blockDim.x) {
-    const int64_t e = (int64_t)g * Z + k;
-    const float lv = fminf(fmaxf(a.lvraw[e], -4.0f), 4.0f);
-    a.z[e] = a.mu[e] + a.eps[e] * expf(0.5f * lv);
-  }
-  __syncthreads();
-  const float *zg = a.z + (int64_t)g * Z;
-  row_linear(zg, a.Wde1, a.bde1, a.he + (int64_t)g * H, H, Z, 1);
-  row_linear(zg, a.Wdn1, a.bdn1, a.hn + (int64_t)g * H, H, Z, 1);
-}
-
 // ---------------------------------------------------------------------------
-// The same chain for graphs of at most 128 nodes and a hidden width of at most 128 (a multiple of
+// The chain for graphs of at most 128 nodes and a hidden width of at most 128 (a multiple of
 // 32), with the graph's activations resident in LDS: every stage reads its operands from LDS (the
 // weights from L2) and leaves its result there for the next one; the copies in the workspace,
 // which the backward reads, are plain stores nobody waits for.  A stage then costs its arithmetic
-// and a barrier instead of a round trip through global memory (2-5 us each in the kernel above).
+// and a barrier instead of a round trip through global memory.
 //
-// The contractions run on the matrix cores, one 32x32 tile of the result per wavefront
-// (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k l>>5] and B[k l>>5][col l&31]).  Within
-// a block of 8 consecutive k the lanes of half h hold k = 4h..4h+3, read as one 16-byte vector,
-// and instruction t of the block contracts k = t and k = 4 + t: a fixed summation order like any
-// other, with vector loads for both operands.
+// The fp32 contractions of the backward run on the matrix cores, one 32x32 tile of the result per
+// wavefront (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k l>>5] and B[k l>>5][col l&31]).
+// Within a block of 8 consecutive k the lanes of half h hold k = 4h..4h+3, read as one 16-byte
+// vector, and instruction t of the block contracts k = t and k = 4 + t: a fixed summation order
+// like any other, with vector loads for both operands.  (The forward's are fp64, further down.)
 // ---------------------------------------------------------------------------
 struct FwdLds {
   int as, hs;                        // row strides (floats) of Ahat and of the activation buffers
@@ -746,28 +685,6 @@ __device__ __forceinline__ f32x16 tile_lds_lds(const float *A, int as, int m0, c
   return acc;
 }
 
-// C tile = A (LDS) * W^T, W (n, k) row-major in global memory with row stride K (K % 8 == 0,
-// K <= 128): the lane's whole row segment is requested before the first multiply
-__device__ __forceinline__ f32x16 tile_lds_w(const float *A, int as, int m0, const float *__restrict__ W,
-                                             int n0, int K) {
-  const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
-  const float *ap = A + (m0 + r) * as + 4 * half;
-  const float4 *wp = reinterpret_cast<const float4 *>(W + (n0 + r) * K + 4 * half);
-  float4 bv[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u)
-    bv[u] = (8 * u < K) ? wp[2 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
-  f32x16 acc = {0};
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    if (8 * u < K) {
-      const float4 av = *reinterpret_cast<const float4 *>(ap + 8 * u);
-      MFMA4(av, bv[u]);
-    }
-  }
-  return acc;
-}
-
 // accumulator register q of lane l is C[(q & 3) + 8 * (q >> 2) + 4 * (l >> 5)][l & 31]
 __device__ __forceinline__ void tile_store(const f32x16 &acc, float *dst, int hs, int m0, int n0,
                                            float *__restrict__ glob, int N, int H) {
@@ -780,64 +697,261 @@ __device__ __forceinline__ void tile_store(const f32x16 &acc, float *dst, int hs
   }
 }
 
-// BatchNorm + ReLU of src + bias (LDS) into dst (LDS) and out (global): the arithmetic of
-// bn_relu_fwd_body, a 64-column slab per 256 threads
+// ---------------------------------------------------------------------------
+// Forward in double precision.  BatchNorm over a handful of near-identical rows (a graph with
+// interchangeable nodes plus its padded rows) divides by a standard deviation of the order of
+// the fp32 rounding of its inputs: every fp32 rounding on the way to that division (of the
+// normalised adjacency, of either contraction, of the layer-1 activations) then moves the
+// gradients by 1e-5 .. 1e-4 of their scale.  The encoder forward of the LDS-resident kernel
+// therefore runs in fp64 from the node features to the pooled vector (operands converted from
+// the fp32 parameters, exact), on the matrix cores: v_mfma_f64_16x16x4_f64, lane l supplies
+// A[row l&15][slot l>>4] and B[slot l>>4][col l&15], result register q of lane l is
+// D[row (l>>4) + 4q][col l&15].  Slot s of instruction t contracts k = s*K/4 + t, so a lane's
+// operands of consecutive instructions are consecutive in memory (vector loads); the summation
+// order is fixed.  The normalised adjacency enters as dinv[i] * (mask * (dinv[k] * T[k])), with
+// the 0/1 mask as bytes in LDS.  What the backward reads (centred pre-activations, activations,
+// statistics, Ahat) is stored rounded to fp32, once.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+struct Acc64 {
+  f64x4 c[2][2];    // 32x32 tile as 2x2 blocks of 16x16
+};
+struct Fwd64Lds {
+  int asb, hs;                                  // bytes per mask row, doubles per activation row
+  size_t o_b, o_a, o_dinv, o_vec, bytes;        // byte offsets
+};
+__host__ __device__ inline Fwd64Lds fwd64_lds_layout(int NP, int H, int Z) {
+  Fwd64Lds L;
+  L.asb = NP + 4;
+  L.hs = H + 2;                                 // rows 16-byte aligned, consecutive rows 4 banks apart
+  const size_t sh = (size_t)(NP * 8 / 256) * 2048;   // double sh[NT/256][4][64]
+  L.o_b = sh < 4096 ? 4096 : sh;                // (the pooling keeps 4 partial rows of doubles there)
+  L.o_a = L.o_b + (size_t)NP * L.hs * 8;
+  L.o_dinv = L.o_a + (size_t)NP * L.asb;
+  L.o_vec = L.o_dinv + (size_t)NP * 8;
+  L.bytes = L.o_vec + (size_t)(H + 3 * Z) * sizeof(float);   // gvec[H], mu[Z], lv[Z], z[Z]
+  return L;
+}
+
+__device__ __forceinline__ void mfma64_2x2(Acc64 &acc, double a0, double a1, double b0, double b1) {
+  acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
+  acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);
+  acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.c[1][0], 0, 0, 0);
+  acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.c[1][1], 0, 0, 0);
+}
+
+// tile (rows m0.., cols n0..) = mask (bytes in LDS, row stride asb) * Bd (doubles in LDS), K % 16 == 0
+__device__ __forceinline__ void tile64_mask_lds(Acc64 &acc, const uint8_t *M, int asb, int m0,
+                                                const double *Bd, int hs, int n0, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4, KQ = K >> 2;
+  const uint8_t *ap0 = M + (m0 + r) * asb + sl * KQ, *ap1 = ap0 + 16 * asb;
+  const double *bp = Bd + (sl * KQ) * hs + n0 + r;
+  for (int t0 = 0; t0 < KQ; t0 += 4) {
+    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(ap0 + t0);
+    const uint32_t w1 = *reinterpret_cast<const uint32_t *>(ap1 + t0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double a0 = (double)((w0 >> (8 * u)) & 0xffu), a1 = (double)((w1 >> (8 * u)) & 0xffu);
+      const double *bq = bp + (t0 + u) * hs;
+      mfma64_2x2(acc, a0, a1, bq[0], bq[16]);
+    }
+  }
+}
+
+// tile = Ad (doubles in LDS) * W^T, W (n, k) fp32 row-major in global memory with row stride K,
+// K % 16 == 0, rows 16-byte aligned; a lane's next weights are requested before it multiplies
+__device__ __forceinline__ void tile64_lds_w(Acc64 &acc, const double *Ad, int hs, int m0,
+                                             const float *__restrict__ W, int n0, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4, KQ = K >> 2;
+  const double *ap0 = Ad + (m0 + r) * hs + sl * KQ, *ap1 = ap0 + 16 * hs;
+  const float *wp0 = W + (n0 + r) * K + sl * KQ, *wp1 = wp0 + 16 * K;
+  float4 w0 = *reinterpret_cast<const float4 *>(wp0), w1 = *reinterpret_cast<const float4 *>(wp1);
+  for (int t0 = 0; t0 < KQ; t0 += 4) {
+    const float4 c0 = w0, c1 = w1;
+    if (t0 + 4 < KQ) {
+      w0 = *reinterpret_cast<const float4 *>(wp0 + t0 + 4);
+      w1 = *reinterpret_cast<const float4 *>(wp1 + t0 + 4);
+    }
+    const double2 a00 = *reinterpret_cast<const double2 *>(ap0 + t0);
+    const double2 a01 = *reinterpret_cast<const double2 *>(ap0 + t0 + 2);
+    const double2 a10 = *reinterpret_cast<const double2 *>(ap1 + t0);
+    const double2 a11 = *reinterpret_cast<const double2 *>(ap1 + t0 + 2);
+    mfma64_2x2(acc, a00.x, a10.x, (double)c0.x, (double)c1.x);
+    mfma64_2x2(acc, a00.y, a10.y, (double)c0.y, (double)c1.y);
+    mfma64_2x2(acc, a01.x, a11.x, (double)c0.z, (double)c1.z);
+    mfma64_2x2(acc, a01.y, a11.y, (double)c0.w, (double)c1.w);
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void tile64_foreach(const Acc64 &acc, int m0, int n0, F f) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        f(m0 + rb * 16 + (lane >> 4) + 4 * q, n0 + cb * 16 + (lane & 15), acc.c[rb][cb][q]);
+}
+
+// BatchNorm + ReLU of buf + bias in place (doubles in LDS), a 64-column slab per 256 threads, 4
+// row lanes per column as in bn_relu_fwd_body; fp32 copies for the backward: the activation
+// (out) and the centred pre-activation (yc)
 template <int NT>
-__device__ __forceinline__ void bn_relu_lds(const float *src, float *dst, int hs, int NP, int N, int H,
-                                            int nx, int train, const float *__restrict__ bias,
-                                            const float *__restrict__ gamma,
-                                            const float *__restrict__ beta,
-                                            const float *__restrict__ run_mean,
-                                            const float *__restrict__ run_var,
-                                            float *__restrict__ out, float *__restrict__ mean_o,
-                                            float *__restrict__ invstd_o, float *__restrict__ var_unb_o,
-                                            double *shd) {
+__device__ __forceinline__ void bn_relu_lds64(double *buf, int hs, int NP, int N, int H, int nx,
+                                              int train, const float *__restrict__ bias,
+                                              const float *__restrict__ gamma,
+                                              const float *__restrict__ beta,
+                                              const float *__restrict__ run_mean,
+                                              const float *__restrict__ run_var,
+                                              float *__restrict__ out, float *__restrict__ yc,
+                                              float *__restrict__ mean_o, float *__restrict__ invstd_o,
+                                              float *__restrict__ var_unb_o, double *shd) {
   const int tid = threadIdx.x, cl = tid & 63, rl = (tid >> 6) & 3, grp = tid >> 8;
   double(*sh)[64] = reinterpret_cast<double(*)[64]>(shd + grp * 256);
   for (int s0 = 0; s0 * 64 < H; s0 += NT / 256) {
     const int c = (s0 + grp) * 64 + cl;
     const bool cv = c < H;
-    const float b = cv ? bias[c] : 0.0f;
-    float mean, invstd;
+    const double b = cv ? (double)bias[c] : 0.0;
+    double mean, invstd;
     if (train) {
       double s = 0.0;
-      if (cv) for (int i = rl; i < nx; i += 4) s += (double)(src[i * hs + c] + b);
+      if (cv) for (int i = rl; i < nx; i += 4) s += buf[i * hs + c] + b;
       s = quad_rows_sum(s, sh, rl, cl);
-      const double mean_d = s / (double)nx;
+      mean = s / (double)nx;
       double q = 0.0;
       if (cv) for (int i = rl; i < nx; i += 4) {
-        const double dlt = (double)(src[i * hs + c] + b) - mean_d;
+        const double dlt = (buf[i * hs + c] + b) - mean;
         q += dlt * dlt;
       }
       q = quad_rows_sum(q, sh, rl, cl);
-      mean = (float)mean_d;
-      invstd = (float)(1.0 / sqrt(q / (double)nx + (double)BN_EPS));
+      invstd = 1.0 / sqrt(q / (double)nx + 1e-5);
       if (cv && rl == 0) {
-        mean_o[c] = mean;
-        invstd_o[c] = invstd;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = (float)invstd;
         var_unb_o[c] = (float)(q / (double)(nx - 1));
       }
     } else {
-      mean = cv ? run_mean[c] : 0.0f;
-      invstd = cv ? 1.0f / sqrtf(run_var[c] + BN_EPS) : 0.0f;
+      mean = cv ? (double)run_mean[c] : 0.0;
+      invstd = cv ? 1.0 / sqrt((double)run_var[c] + 1e-5) : 0.0;
       if (cv && rl == 0) {
-        mean_o[c] = mean;
-        invstd_o[c] = invstd;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = (float)invstd;
       }
     }
     if (cv) {
-      const float ga = gamma[c], be = beta[c];
+      const double ga = (double)gamma[c], be = (double)beta[c];
       for (int i = rl; i < NP; i += 4) {
-        float o = 0.0f;
+        double o = 0.0, xc = 0.0;
         if (i < nx) {
-          const float xh = ((src[i * hs + c] + b) - mean) * invstd;
-          o = fmaxf(xh * ga + be, 0.0f);
+          xc = (buf[i * hs + c] + b) - mean;
+          o = fmax(xc * invstd * ga + be, 0.0);
         }
-        dst[i * hs + c] = o;
-        if (i < N) out[(int64_t)i * H + c] = o;
+        buf[i * hs + c] = o;
+        if (i < N) {
+          out[(int64_t)i * H + c] = (float)o;
+          yc[(int64_t)i * H + c] = (float)xc;
+        }
       }
     }
   }
+}
+
+// The chain for any size (N <= 1024), a work-group per graph: the same fp64 arithmetic with plain fma
+// chains, activations through two fp64 buffers in global memory (a work-group finds its own stores
+// after a barrier).
+__global__ __launch_bounds__(256) void model_fwd_graph_kernel(ModelFwdArgs a) {
+  __shared__ double sh[4][64];
+  __shared__ double dinv[1024];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int N = a.N, F = a.F, H = a.H, Z = a.Z;
+  const int64_t NH = (int64_t)N * H;
+  const int nx = a.n_x[g], R = a.R[g];
+  const float *Ag = a.adj + (int64_t)g * N * N;
+  // (no __restrict__: both are written and read again behind a barrier)
+  double *T = a.T64 + g * NH, *Y = a.Y64 + g * NH;
+  if (g == 0 && tid == 0) a.bn_mode[0] = a.train;   // which statistics: the backward reads it
+  for (int i = tid; i < N; i += 256) {
+    int cnt = 0;
+    if (i < R)
+      for (int j = 0; j < R; ++j) cnt += (j != i && Ag[(int64_t)i * N + j] != 0.0f) ? 1 : 0;
+    dinv[i] = (i < nx) ? 1.0 / sqrt(1.0 + (double)cnt) : 0.0;
+  }
+  __syncthreads();
+  auto edge = [&](int i, int k) -> bool {
+    return i < nx && k < nx && (i == k || (i < R && k < R && Ag[(int64_t)i * N + k] != 0.0f));
+  };
+  {
+    float *Og = a.Ahat + (int64_t)g * N * N;
+    for (int e = tid; e < N * N; e += 256) {
+      const int i = e / N, j = e - i * N;
+      Og[e] = edge(i, j) ? (float)(dinv[i] * dinv[j]) : 0.0f;
+    }
+  }
+  // buffer Y <- dinv[row] * sum over the row's neighbours k of T[k] (T holds dinv[k] * linear output)
+  auto aggregate = [&]() {
+    for (int e = tid; e < N * H; e += 256) {
+      const int i = e / H, c = e - i * H;
+      double acc = 0.0;
+      if (i < nx)
+        for (int k = 0; k < nx; ++k)
+          if (edge(i, k)) acc += T[(int64_t)k * H + c];
+      Y[e] = dinv[i] * acc;
+    }
+    __syncthreads();
+  };
+  // layer 1
+  {
+    const float *xg = a.x + (int64_t)g * N * F;
+    for (int e = tid; e < N * H; e += 256) {
+      const int i = e / H, c = e - i * H;
+      double acc = 0.0;
+      for (int f = 0; f < F; ++f) acc = fma((double)xg[(int64_t)i * F + f], (double)a.W1[(int64_t)c * F + f], acc);
+      a.H0a[g * NH + e] = (float)acc;
+      T[e] = acc * dinv[i];
+    }
+  }
+  __syncthreads();
+  aggregate();
+  bn_relu_lds64<256>(Y, H, N, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
+                     a.Y1 + g * NH, a.mean1 + (int64_t)g * H, a.invstd1 + (int64_t)g * H,
+                     a.varu1 + (int64_t)g * H, &sh[0][0]);
+  __syncthreads();
+  // layer 2
+  for (int e = tid; e < N * H; e += 256) {
+    const int i = e / H, c = e - i * H;
+    double acc = 0.0;
+    for (int k = 0; k < H; ++k) acc = fma(Y[(int64_t)i * H + k], (double)a.W2[(int64_t)c * H + k], acc);
+    a.H0b[g * NH + e] = (float)acc;
+    T[e] = acc * dinv[i];
+  }
+  __syncthreads();
+  aggregate();
+  bn_relu_lds64<256>(Y, H, N, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
+                     a.Y2 + g * NH, a.mean2 + (int64_t)g * H, a.invstd2 + (int64_t)g * H,
+                     a.varu2 + (int64_t)g * H, &sh[0][0]);
+  __syncthreads();
+  for (int c = tid; c < H; c += 256) {
+    double s0 = 0.0;
+    for (int i = 0; i < nx; ++i) s0 += Y[(int64_t)i * H + c];
+    a.gvec[(int64_t)g * H + c] = (float)(s0 / (double)R);
+  }
+  __syncthreads();
+  // heads, reparameterisation, first decoder layers: one row per graph
+  const float *gv = a.gvec + (int64_t)g * H;
+  row_linear(gv, a.Wmu, a.bmu, a.mu + (int64_t)g * Z, Z, H, 0);
+  row_linear(gv, a.Wlv, a.blv, a.lvraw + (int64_t)g * Z, Z, H, 0);
+  __syncthreads();
+  for (int k = threadIdx.x; k < Z; k += blockDim.x) {
+    const int64_t e = (int64_t)g * Z + k;
+    const float lv = fminf(fmaxf(a.lvraw[e], -4.0f), 4.0f);
+    a.z[e] = a.mu[e] + a.eps[e] * expf(0.5f * lv);
+  }
+  __syncthreads();
+  const float *zg = a.z + (int64_t)g * Z;
+  row_linear(zg, a.Wde1, a.bde1, a.he + (int64_t)g * H, H, Z, 1);
+  row_linear(zg, a.Wdn1, a.bdn1, a.hn + (int64_t)g * H, H, Z, 1);
 }
 
 // out[n] = [relu](bias[n] + sum_k in[k] * W[n*K + k]), in[] in LDS, K % 4 == 0, for the rows
@@ -858,19 +972,22 @@ __device__ __forceinline__ float row_dot4(const float *in, const float *__restri
 template <int NP>
 __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a) {
   constexpr int NT = NP * 8;
-  extern __shared__ __align__(16) float lds[];
+  extern __shared__ __align__(16) unsigned char lds_raw[];
   const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const int N = a.N, F = a.F, H = a.H, Z = a.Z;
-  const FwdLds L = fwd_lds_layout(NP, H, Z);
-  const int AS = L.as, HS = L.hs;
-  double *shd = reinterpret_cast<double *>(lds);
-  float *Ah = lds + L.o_ah, *b = lds + L.o_b;
-  float *dinv = lds + L.o_vec, *gv = dinv + NP, *mu_s = gv + H, *lv_s = mu_s + Z, *z_s = lv_s + Z;
+  const Fwd64Lds L = fwd64_lds_layout(NP, H, Z);
+  const int ASB = L.asb, HS = L.hs;
+  double *shd = reinterpret_cast<double *>(lds_raw);
+  double *b = reinterpret_cast<double *>(lds_raw + L.o_b);
+  uint8_t *Am = lds_raw + L.o_a;
+  double *dinv = reinterpret_cast<double *>(lds_raw + L.o_dinv);
+  float *gv = reinterpret_cast<float *>(lds_raw + L.o_vec), *mu_s = gv + H, *lv_s = mu_s + Z,
+        *z_s = lv_s + Z;
   const int nx = a.n_x[g], R = a.R[g];
   const int64_t NH = (int64_t)N * H;
   if (g == 0 && tid == 0) a.bn_mode[0] = a.train;   // which statistics: the backward reads it
 
-  // degrees: 8 lanes per row count the row's neighbours (exact in fp32 in any order)
+  // degrees: 8 lanes per row count the row's neighbours (exact in any order)
   {
     const int i = tid >> 3, sub = tid & 7;
     const float *Ag = a.adj + (int64_t)g * N * N;
@@ -881,35 +998,35 @@ __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a
     cnt += __shfl_xor(cnt, 1, 64);
     cnt += __shfl_xor(cnt, 2, 64);
     cnt += __shfl_xor(cnt, 4, 64);
-    if (sub == 0) dinv[i] = (i < nx) ? 1.0f / sqrtf(1.0f + cnt) : 0.0f;
+    if (sub == 0) dinv[i] = (i < nx) ? 1.0 / sqrt(1.0 + (double)cnt) : 0.0;
   }
-  // X W1^T (K = F, a handful: plain fma chains), rows >= N of the buffer zero
+  __syncthreads();
+  // X W1^T (K = F: plain fma chains), scaled by dinv[row] for the aggregation; rows >= n_x zero
   {
     const float *xg = a.x + (int64_t)g * N * F;
     for (int e = tid; e < NP * H; e += NT) {
       const int i = e / H, c = e - i * H;
-      float acc = 0.0f;
+      double acc = 0.0;
       if (i < N) {
-        for (int f = 0; f < F; ++f) acc = __fmaf_rn(xg[i * F + f], a.W1[c * F + f], acc);
-        a.H0a[g * NH + e] = acc;
+        for (int f = 0; f < F; ++f) acc = fma((double)xg[i * F + f], (double)a.W1[c * F + f], acc);
+        a.H0a[g * NH + e] = (float)acc;
       }
-      b[i * HS + c] = acc;
+      b[i * HS + c] = acc * dinv[i];
     }
   }
-  __syncthreads();
+  // adjacency mask with self loops on the n_x live rows; Ahat (fp32) for the backward
   {
     const float *Ag = a.adj + (int64_t)g * N * N;
     float *Og = a.Ahat + (int64_t)g * N * N;
     for (int e = tid; e < NP * NP; e += NT) {
       const int i = e / NP, j = e - i * NP;
-      float v = 0.0f;
+      bool m = false;
       if (i < nx && j < nx) {
-        if (i == j) v = 1.0f;
-        else if (i < R && j < R) v = (Ag[(int64_t)i * N + j] != 0.0f) ? 1.0f : 0.0f;
+        if (i == j) m = true;
+        else if (i < R && j < R) m = Ag[(int64_t)i * N + j] != 0.0f;
       }
-      v = dinv[i] * v * dinv[j];
-      Ah[i * AS + j] = v;
-      if (i < N && j < N) Og[(int64_t)i * N + j] = v;
+      Am[i * ASB + j] = m ? 1 : 0;
+      if (i < N && j < N) Og[(int64_t)i * N + j] = m ? (float)(dinv[i] * dinv[j]) : 0.0f;
     }
   }
   __syncthreads();
@@ -918,39 +1035,52 @@ __global__ __launch_bounds__(NP * 8, 4) void model_fwd_lds_kernel(ModelFwdArgs a
   const int tn = H / 32, tiles = (NP / 32) * tn;
   const bool has_tile = wave < tiles;
   const int m0 = (wave / tn) * 32, n0 = (wave % tn) * 32;
-  f32x16 acc;
+  Acc64 acc;
+  auto zero = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc.c[u >> 1][u & 1] = f64x4{0.0, 0.0, 0.0, 0.0};
+  };
+  auto aggregate = [&]() {      // buffer <- dinv[row] * (mask * buffer)
+    zero();
+    if (has_tile) tile64_mask_lds(acc, Am, ASB, m0, b, HS, n0, NP);
+    __syncthreads();
+    if (has_tile) tile64_foreach(acc, m0, n0, [&](int row, int col, double v) { b[row * HS + col] = dinv[row] * v; });
+    __syncthreads();
+  };
   // layer 1: Y1 = Ahat * H0a;  H1 = relu(bn(Y1 + bias))
-  if (has_tile) acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
-  __syncthreads();
-  if (has_tile) tile_store(acc, b, HS, m0, n0, a.Y1 + g * NH, N, H);
-  __syncthreads();
-  bn_relu_lds<NT>(b, b, HS, NP, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
-                  a.mean1 + (int64_t)g * H, a.invstd1 + (int64_t)g * H, a.varu1 + (int64_t)g * H, shd);
+  aggregate();
+  bn_relu_lds64<NT>(b, HS, NP, N, H, nx, a.train, a.b1, a.g1, a.be1, a.rm1, a.rv1, a.H1 + g * NH,
+                    a.Y1 + g * NH, a.mean1 + (int64_t)g * H, a.invstd1 + (int64_t)g * H,
+                    a.varu1 + (int64_t)g * H, shd);
   __syncthreads();
   // layer 2: H0b = H1 * W2^T;  Y2 = Ahat * H0b;  H2 = relu(bn(Y2 + bias))
-  if (has_tile) acc = tile_lds_w(b, HS, m0, a.W2, n0, H);
+  zero();
+  if (has_tile) tile64_lds_w(acc, b, HS, m0, a.W2, n0, H);
   __syncthreads();
-  if (has_tile) tile_store(acc, b, HS, m0, n0, a.H0b + g * NH, N, H);
+  if (has_tile) {
+    float *glob = a.H0b + g * NH;
+    tile64_foreach(acc, m0, n0, [&](int row, int col, double v) {
+      b[row * HS + col] = dinv[row] * v;
+      if (row < N) glob[(int64_t)row * H + col] = (float)v;
+    });
+  }
   __syncthreads();
-  if (has_tile) acc = tile_lds_lds(Ah, AS, m0, b, HS, n0, NP);
+  aggregate();
+  bn_relu_lds64<NT>(b, HS, NP, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
+                    a.Y2 + g * NH, a.mean2 + (int64_t)g * H, a.invstd2 + (int64_t)g * H,
+                    a.varu2 + (int64_t)g * H, shd);
   __syncthreads();
-  if (has_tile) tile_store(acc, b, HS, m0, n0, a.Y2 + g * NH, N, H);
-  __syncthreads();
-  bn_relu_lds<NT>(b, b, HS, NP, N, H, nx, a.train, a.b2, a.g2, a.be2, a.rm2, a.rv2, a.H2 + g * NH,
-                  a.mean2 + (int64_t)g * H, a.invstd2 + (int64_t)g * H, a.varu2 + (int64_t)g * H, shd);
-  __syncthreads();
-  // pooled vector: the four row lanes of pool_fwd_body, in its order
+  // pooled vector: four row lanes per column, then rounded to fp32 once
   {
-    float *shf = reinterpret_cast<float *>(shd);          // [4][128]
     for (int e = tid; e < 4 * H; e += NT) {
       const int rl = e / H, c = e - rl * H;
-      float s = 0.0f;
+      double s = 0.0;
       for (int i = rl; i < nx; i += 4) s += b[i * HS + c];
-      shf[rl * 128 + c] = s;
+      shd[rl * 128 + c] = s;
     }
     __syncthreads();
     for (int c = tid; c < H; c += NT) {
-      const float v = ((shf[c] + shf[128 + c]) + (shf[256 + c] + shf[384 + c])) / (float)R;
+      const float v = (float)(((shd[c] + shd[128 + c]) + (shd[256 + c] + shd[384 + c])) / (double)R);
       gv[c] = v;
       a.gvec[(int64_t)g * H + c] = v;
     }
@@ -992,7 +1122,7 @@ int launch_model_fwd_graph(const ModelFwdArgs &a, int B, hipStream_t s) {
     return check_launch("model_fwd_graph");
   }
   const int NP = a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 128);
-  const size_t lds = fwd_lds_layout(NP, a.H, a.Z).bytes;
+  const size_t lds = fwd64_lds_layout(NP, a.H, a.Z).bytes;
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "model_fwd: %zu bytes of LDS", lds);
   auto launch = [&](auto kernel) -> int {
     if (lds > 48 * 1024) {
@@ -1062,8 +1192,6 @@ __device__ __forceinline__ void bn_relu_bwd_lds(
   for (int s0 = 0; s0 * 64 < H; s0 += NT / 256) {
     const int c = (s0 + grp) * 64 + cl;
     const bool cv = c < H;
-    const float b = cv ? bias[c] : 0.0f;
-    const float mu = cv ? mean[c] : 0.0f;
     const float is = cv ? invstd[c] : 0.0f;
     // a lane's rows stay in registers between the two passes while they fit (16 rows at most);
     // the 32 rows of the largest size are read again (dsrc may be dst: a lane reads an element
@@ -1075,7 +1203,7 @@ __device__ __forceinline__ void bn_relu_bwd_lds(
       d = 0.0f;
       if (cv && i < nx) {
         const int e = i * H + c;
-        x = (Yg[e] + b) - mu;
+        x = Yg[e];                                  // centred by the forward
         const float din = dsrc ? dsrc[i * hs + c] : dgv[c] * inv_r;
         d = Og[e] > 0.0f ? din : 0.0f;
       }

@@ -55,6 +55,7 @@ struct ModelFwdArgs {
   float *Ahat, *H0a, *Y1, *H1, *H0b, *Y2, *H2;
   float *mean1, *invstd1, *varu1, *mean2, *invstd2, *varu2;
   float *gvec, *mu, *lvraw, *z, *he, *hn;
+  double *T64, *Y64;   // (B,N,H) each: fp64 activations of the any-size kernel
   int32_t *bn_mode;
   int N, F, H, Z, train;
 };
@@ -84,7 +85,7 @@ int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, 
 // BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics
 // (written to mean / invstd / var_unbiased, each (B,H)); else running statistics.
 // mode_out (device, nullable) receives `train`: launch_bn_relu_bwd of the same batch reads it.
-int launch_bn_relu_fwd(const float *Y, const float *bias, const float *gamma, const float *beta,
+int launch_bn_relu_fwd(float *Y, const float *bias, const float *gamma, const float *beta,
                        const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
                        int H, int train, float *out, float *mean, float *invstd, float *var_unb,
                        int32_t *mode_out, hipStream_t s);

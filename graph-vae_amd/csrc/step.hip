@@ -339,6 +339,9 @@ static int forward_model(const gvae_dims *d, const float *d_params, float *d_bn_
     a.Wde1 = P.p[GVAE_P_DE1_W]; a.bde1 = P.p[GVAE_P_DE1_B]; a.Wdn1 = P.p[GVAE_P_DN1_W];
     a.bdn1 = P.p[GVAE_P_DN1_B];
     a.Ahat = w.Ahat; a.H0a = w.H0a; a.Y1 = w.Y1; a.H1 = w.H1; a.H0b = w.H0b; a.Y2 = w.Y2; a.H2 = w.H2;
+    // fp64 activations of the any-size kernel: in buffers only the backward of this batch writes
+    // (dAct + dY and dH0 .. dH0_2 are each at least 2 * B*N*H contiguous floats, 256-byte aligned)
+    a.T64 = reinterpret_cast<double *>(w.dAct); a.Y64 = reinterpret_cast<double *>(w.dH0);
     a.mean1 = w.mean1; a.invstd1 = w.invstd1; a.varu1 = w.varu1;
     a.mean2 = w.mean2; a.invstd2 = w.invstd2; a.varu2 = w.varu2;
     a.gvec = w.gvec; a.mu = w.mu; a.lvraw = w.lvraw; a.z = w.z; a.he = w.he; a.hn = w.hn;

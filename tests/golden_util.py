@@ -189,6 +189,53 @@ def check_grads(got: dict, ref: dict, truth: dict | None = None, tol: float = 1e
         assert err <= tol * max(np.abs(r).max(), 1e-30) + slack, (name, err, float(np.abs(r).max()), slack)
 
 
+def check_grads_accurate(got: dict, ref: dict, truth: dict, tol: float = 1e-5):
+    """The bar of the GPU step: each gradient tensor is within `tol` (relative to the tensor's
+    largest entry) of the float64 value, or at least as close to it as the reference's own fp32
+    evaluation is (`tol` + the reference's distance).  The reference's fp32 gradients sit up to
+    3e-4 from the float64 value on ill-conditioned BatchNorm columns; the GPU computes the encoder
+    forward in fp64 and sits 1e-7 .. 1e-6 from it there.  Also required: within `tol` + twice the
+    reference's distance of the reference itself (implied by the first, kept as a cross-check).
+    The two GCN biases have a true gradient of zero (a training-mode BatchNorm cancels any
+    per-column constant) and are only required to be noise, as in check_grads."""
+    gmax = max(float(np.abs(v).max()) for v in ref.values())
+    for name, r in ref.items():
+        g, r, t = (np.asarray(a, np.float64) for a in (got[name], r, truth[name]))
+        if name in ZERO_GRAD_PARAMS:
+            assert np.abs(g).max() <= 20 * tol * gmax, name
+            continue
+        scale = max(float(np.abs(t).max()), 1e-30)
+        d_got, d_ref = float(np.abs(g - t).max()), float(np.abs(r - t).max())
+        print(f"  grad {name:20s} |got-f64| {d_got / scale:.2e}  |ref-f64| {d_ref / scale:.2e}  "
+              f"|got-ref| {np.abs(g - r).max() / scale:.2e}")
+        assert d_got <= tol * scale + d_ref, (name, d_got / scale, d_ref / scale)
+        assert float(np.abs(g - r).max()) <= tol * scale + 2.0 * d_ref, name
+
+
+def truth64_steps(G, n_steps: int = 3):
+    """The golden optimiser steps (reference train_ddp.py:282-292,316) recomputed in float64 by
+    the CPU restatement: per step (loss, gradient norm before clipping), and the parameters
+    after the last step."""
+    from oracle import ref_step as R
+    lr, wd, beta0, beta_final, clip_max, anneal = G.opt["hparams"].tolist()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        st = R.make_trainable({k: (v.double() if v.is_floating_point() else v.clone())
+                               for k, v in G.state0.items()})
+        graphs = [SimpleNamespace(x=g.x.double(), adj_dense=g.adj_dense.double(),
+                                  num_real_nodes=g.num_real_nodes) for g in G.graphs]
+        opt = torch.optim.Adam([st[n] for n in R.PARAM_NAMES], lr=lr, weight_decay=wd)
+        steps = []
+        for gs in range(n_steps):
+            loss, _res, gn = R.train_step(st, opt, graphs, [e.double() for e in G.opt["eps"][gs]], gs,
+                                          int(anneal), lr, beta0, beta_final, clip_max)
+            steps.append((loss, gn))
+        return steps, {k: st[k].detach().numpy().copy() for k in R.PARAM_NAMES}
+    finally:
+        torch.set_default_dtype(old)
+
+
 def perm_equivalent(perm, perm_ref, X, tol=1e-5):
     """True if `perm` equals the reference permutation, or both are optimal for X up to
     rounding (ties between assignments of near-identical value: an end-to-end run reaches
@@ -209,13 +256,15 @@ def check_params_after_adam(got: dict, ref: dict, lr: float, tol: float = 1e-4):
     """Parameters after the three golden optimiser steps.  Adam divides each gradient by
     its own running magnitude, so an entry whose gradient is pure rounding noise (the GCN
     biases, see check_grads) moves by +-lr per step in a direction set by that noise: those
-    two tensors are only required to stay within 3*lr of the reference.  Everything else
-    must agree to `tol` of the tensor's scale."""
+    two tensors are only required to stay within 3*lr of the reference, and so are the
+    BatchNorm running means, which contain those biases (the mean of conv output + bias; the
+    running statistics after ONE step are held to 1e-5 by the forward tests).  Everything
+    else must agree to `tol` of the tensor's scale."""
     for name, r in ref.items():
         if name not in got:
             continue
         g, r = np.asarray(got[name], np.float64), np.asarray(r, np.float64)
-        if name in ZERO_GRAD_PARAMS:
+        if name in ZERO_GRAD_PARAMS or name.endswith("running_mean"):
             assert np.abs(g - r).max() <= 3.0 * lr * 1.01, name
         else:
             assert np.abs(g - r).max() <= tol * max(np.abs(r).max(), 1e-3), (name, float(np.abs(g - r).max()))

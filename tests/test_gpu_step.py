@@ -11,28 +11,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import (check_grads, check_params_after_adam, load_g5, load_g10, load_g12,  # noqa: E402
-                         perm_equivalent, rel_err, truth64)
+from golden_util import (check_grads_accurate, check_params_after_adam, load_g5, load_g10,  # noqa: E402
+                         load_g12, perm_equivalent, rel_err, truth64, truth64_steps)
 from oracle import ref_step as R  # noqa: E402  (checker only)
 
 CASES = ["grid_deg", "grid_id", "rand_deg", "rand_id"]
 TOL = 1e-5
-# conv1.lin.weight of the legacy-loss case is a (H, 1) tensor whose entries are sums with heavy
-# cancellation once the padded node logits stop contributing: fp32 evaluations of the same
-# formula differ by ~4e-5 of its scale (the reference sits 6e-6 from the float64 value).
-LEGACY_GRAD_TOL = 5e-5
 DEV = "cuda:0"
-# Gradient tolerance per golden case (on top of it: 1 x the reference's own distance from the
-# float64 value, golden_util.check_grads).  grid/deg contains the 2x2 grid graph, whose four
-# real nodes are equivalent and whose five padded rows form a second cluster 3.6e-3 away: a
-# layer-2 BatchNorm column there has variance 1.3e-5 (about the BatchNorm eps), the
-# normalisation divides fp32 values that agree in their first three digits, and the pooled
-# vector is only determined to ~5e-5 in fp32 whatever the summation order (the reference's own
-# gradients sit 4e-5..3e-4 from their float64 values on that case, the GPU's 3e-4..6e-4; the
-# inputs of that BatchNorm are within 3e-7 of float64 on the GPU).  Losses, probabilities and
-# permutations keep the 1e-5 bar on every case.
-GRAD_TOL = {"grid_deg": 7e-4}
-
 
 def _model_and_batch(G, matching="auto"):
     from graphvae.data import collate
@@ -77,7 +62,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, case, matching):
 
     out["loss"].backward()
     got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
-    check_grads(got, G.grads, truth64(G), GRAD_TOL.get(case, TOL))
+    check_grads_accurate(got, G.grads, truth64(G), TOL)
     sd = model.state_dict()
     for k, v in G.state1.items():
         assert rel_err(sd[k].cpu().numpy(), v) < TOL, k
@@ -129,6 +114,7 @@ def test_three_optimizer_steps_vs_reference_golden(golden_dir, case):
     model, batch, _ = _model_and_batch(G)
     model.train()
     step = TrainStep(model, lr, wd, clip_max)
+    t_steps, t_state = truth64_steps(G)
     for gs in range(3):
         frac = min(1.0, gs / anneal)
         beta = beta0 + (beta_final - beta0) * frac
@@ -136,10 +122,20 @@ def test_three_optimizer_steps_vs_reference_golden(golden_dir, case):
         out4 = step(batch, beta, frac, eps=eps).tolist()
         ref = G.opt["losses"][gs]
         assert abs(out4[0] + beta * out4[1] - ref[0]) <= 2e-5 * abs(ref[0]), (gs, out4, ref)
-        gn_tol = 1e-4 if case not in GRAD_TOL else GRAD_TOL[case]
-        assert abs(step.grad_norm.item() - ref[3]) <= gn_tol * abs(ref[3]), (gs, step.grad_norm.item(), ref[3])
+        # Gradient norm.  Steps 0 and 1 start from the initial parameters (the warm-up makes the
+        # learning rate of step 0 zero): within 1e-5 of the float64 value, or as close to it as
+        # the reference is.  From step 2 on the parameters have taken an Adam update, which
+        # divides each gradient entry by its own magnitude: an entry whose sign is rounding noise
+        # moves by +-lr in whichever direction the noise points, in fp32 and in float64 alike, so
+        # the three trajectories are 1e-5 .. 1e-4 apart whatever the accuracy of a single step.
+        gn, gn_t = step.grad_norm.item(), t_steps[gs][1]
+        print(f"  step {gs}: |gn-f64| {abs(gn - gn_t) / gn_t:.2e}  |ref-f64| {abs(ref[3] - gn_t) / gn_t:.2e}")
+        if gs < 2:
+            assert abs(gn - gn_t) <= 1e-5 * gn_t + abs(ref[3] - gn_t), (gs, gn, ref[3], gn_t)
+        else:
+            assert abs(gn - gn_t) <= 1e-4 * gn_t and abs(gn - ref[3]) <= 1e-4 * gn_t, (gs, gn, ref[3], gn_t)
     got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    check_params_after_adam(got, G.opt["state3"], lr, tol=1e-4 if case not in GRAD_TOL else 5e-3)
+    check_params_after_adam(got, G.opt["state3"], lr, tol=1e-4)
 
 
 @pytest.mark.parametrize("matching", ["fused", "stream"])
@@ -250,7 +246,7 @@ def test_forward_old_vs_reference_golden(golden_dir, matching):
         assert perm_equivalent(perm[g, :len(p)], p, X[g])
     (out["rec"] + out["kl"]).backward()
     got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
-    check_grads(got, L.grads, truth64(G, legacy_mask=True), LEGACY_GRAD_TOL)
+    check_grads_accurate(got, L.grads, truth64(G, legacy_mask=True), TOL)
     torch.manual_seed(0)
     out2 = model.forward_old(batch)
     assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
@@ -294,7 +290,7 @@ def test_individual_rho_vs_reference_golden(golden_dir, matching):
         if n.startswith("dec_node"):
             assert not got[n].any()
             want[n] = got[n]
-    check_grads(got, want, truth64(G, individual_rho=True), TOL)
+    check_grads_accurate(got, want, truth64(G, individual_rho=True), TOL)
     torch.manual_seed(0)
     out2 = model.forward_individual_rho(batch)
     assert set(out2) == {"rec", "kl", "max_logit", "logvar_max"}
@@ -362,7 +358,7 @@ def test_default_sizes_vs_cpu_restatement(feature_type, N, B, kind):
     # float64 yardstick for the CPU restatement's own rounding
     G = type("G", (), {})()
     G.state0, G.graphs, G.eps = state0, graphs, [eps[g:g + 1] for g in range(B)]
-    check_grads(got, ref_g, truth64(G), TOL)
+    check_grads_accurate(got, ref_g, truth64(G), TOL)
 
 
 def test_chunked_streamed_matching_equals_one_chunk():
