@@ -12,8 +12,13 @@
 //     order that is unassigned if there is one, otherwise the first one in list order.
 // The column scan (the O(n) inner loop) is spread over the 64 lanes; the selection
 // rule above is evaluated with wave-wide min/max reductions, which is equivalent to
-// the sequential scan.  Dual variables, distances, the path and the list order live in
-// registers; only the fp32 matrix itself is in LDS.
+// the sequential scan: "among the columns at the minimum distance, the last unassigned one in
+// list order, else the first one in list order" becomes one integer maximum over the keys
+//   unassigned: 0x10000 + pos      assigned: 0xFFFF - pos      (list positions are unique).
+// Dual variables, distances, the path and the list order live in registers, the sets of
+// scanned rows / columns are wave-uniform bit masks; only the fp32 matrix itself is in LDS.
+// The wave-uniform scalars (current row, the chosen column, the sink) move between lanes with
+// readlane / DPP; there is no barrier in the solver.
 //
 // Included by lsap.hip (the stand-alone kernel) and matching.hip (the S-free MPM kernel, which
 // solves a graph's assignment as its epilogue, from the X it already holds in LDS).
@@ -82,144 +87,171 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// value of a per-lane array element held by lane (idx & 63), chunk (idx >> 6); idx is uniform
-template <int NCH>
-__device__ __forceinline__ int pick_i32(const int (&a)[NCH], int idx) {
-  const int l = idx & 63;
-  int r = __builtin_amdgcn_readlane(a[0], l);
-  if constexpr (NCH == 2) {
-    if (idx >= 64) r = __builtin_amdgcn_readlane(a[1], l);
-  }
-  return r;
-}
-template <int NCH>
-__device__ __forceinline__ double pick_f64(const double (&a)[NCH], int idx) {
-  const int l = idx & 63;
-  double r = read_lane_f64(a[0], l);
-  if constexpr (NCH == 2) {
-    if (idx >= 64) r = read_lane_f64(a[1], l);
-  }
-  return r;
-}
-
-// One wavefront per graph, the whole solver state in registers: lane l owns columns and rows
-// l (and l + 64 when NCH == 2).  Column state: dual v, tentative distance spc, predecessor
-// path, row4col, and pos = the column's position in the list of unscanned columns (-1 once
-// scanned).  Row state: dual u, col4row, the scanned-row flag.  Only the cost matrix (= X,
-// negated on read) sits in LDS.  The wave-uniform scalars (current row i, the chosen column,
-// the sink) move between lanes with readlane / DPP; there is no barrier in the solver.
-//
-// The sequential rule "among the columns at the minimum distance, the last unassigned one in
-// list order, else the first one in list order" becomes one integer maximum over the keys
-//   unassigned: 0x10000 + pos      assigned: 0xFFFF - pos      (list positions are unique)
-template <int NCH, int LANES = 64>
-__device__ __forceinline__ int lsap_solve(const float *cost, int n, int ld, int lane,
-                                          int (&col4row)[NCH]) {
-  double u[NCH], v[NCH], spc[NCH];
-  int path[NCH], row4col[NCH], pos[NCH], ccol[NCH];
-  // scanned rows / columns of the current augmentation as wave-uniform bit masks
-  unsigned long long sr[NCH], sc[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    u[c] = 0.0; v[c] = 0.0; spc[c] = INFINITY;
-    path[c] = -1; row4col[c] = -1; col4row[c] = -1; pos[c] = -1;
-    ccol[c] = min(c * 64 + lane, n - 1);     // lanes past the matrix re-read its last column
-  }
+// The solver for at most 64 columns (lane l owns column l and row l), written for the latency
+// of one search step, which is what the kernel's run time is made of (a graph takes about n^2/2
+// steps, one after the other: SciPy's solver starts every row's search from scratch and, on the
+// near-rank-one matrices the MPM converges to, scans every assigned column before it reaches a
+// free one).  A step costs its instructions (a lone wavefront issues one every 4-5 cycles) plus
+// about 25 cycles each time a value computed by the vector unit is consumed by the scalar unit.
+// Hence: the set of unscanned columns is a wave-uniform bit mask in scalar registers (it costs a
+// vector lane nothing to test, and removing a column is one scalar instruction) instead of a
+// per-lane test of the list position; scanned columns keep +inf as their reduction key, so the
+// comparison with the minimum needs no second mask; the list position of a scanned column is
+// left stale (it is never read again).
+template <int LANES>
+__device__ __forceinline__ int lsap_solve_1(const float *cost, int n, int ld, int lane, int &col4row) {
+  double u = 0.0, v = 0.0;
+  int path = -1, row4col = -1;
+  col4row = -1;
+  const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  const float *ccol = cost + min(lane, n - 1);      // lanes past the matrix re-read its last column
   for (int cur = 0; cur < n; ++cur) {
-    double minVal = 0.0;
+    double minVal = 0.0, spc = INFINITY;
     int i = cur, num_remaining = n, sink = -1;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 64 + lane;
-      pos[c] = col < n ? n - 1 - col : -1;   // the list starts as n-1, n-2, ..., 0
-      sr[c] = 0ull; sc[c] = 0ull;
-      spc[c] = INFINITY;
-    }
-    // The inner loop is a single dependent chain executed by one wavefront: it is written
-    // without per-lane control flow (selects instead of branches, the cost row read by every
-    // lane), which is what its latency is made of.
-    while (sink == -1) {
-      if (NCH == 1 || i < 64) sr[0] |= 1ull << (i & 63);
-      else sr[NCH - 1] |= 1ull << (i & 63);
-      const double ui = pick_f64<NCH>(u, i);
-      const float *crow = cost + i * ld;
-      double lowest = INFINITY;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const bool act = pos[c] >= 0;
-        const double r = minVal + (double)(-crow[ccol[c]]) - ui - v[c];
-        const bool upd = act && r < spc[c];
-        spc[c] = upd ? r : spc[c];
-        path[c] = upd ? i : path[c];
-        lowest = min1_f64(act ? spc[c] : INFINITY, lowest);
-      }
-      lowest = wave_min_f64<LANES>(lowest);
-      if (lowest == INFINITY) return 1;      // infeasible
-      // columns at the minimum distance: usually exactly one, which the ballot names directly;
-      // only a tie needs the second wave-wide reduction over the selection keys
-      bool at_min[NCH];
-      unsigned long long m_at[NCH];
-      int n_at = 0;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        at_min[c] = pos[c] >= 0 && spc[c] == lowest;
-        m_at[c] = __ballot(at_min[c]);
-        n_at += __popcll(m_at[c]);
-      }
+    int pos = n - 1 - lane;                          // the list starts as n-1, n-2, ..., 0
+    unsigned long long act = valid, sr = 0ull, sc = 0ull;
+    do {
+      sr |= 1ull << i;
+      const float c = ccol[i * ld];
+      const double ui = read_lane_f64(u, i);
+      const double r = minVal + (double)(-c) - ui - v;
+      const bool a = __builtin_amdgcn_inverse_ballot_w64(act);
+      const bool upd = a && r < spc;
+      spc = upd ? r : spc;
+      path = upd ? i : path;
+      const double key = a ? spc : INFINITY;
+      const double lowest = wave_min_f64<LANES>(key);
+      // columns at the minimum: usually exactly one, which the ballot names directly (scanned
+      // columns hold +inf, so they only match when nothing is reachable: the infeasible case)
+      const unsigned long long m_at = __ballot(key == lowest);
       int j;
-      if (n_at == 1) {
-        j = m_at[0] ? __ffsll((long long)m_at[0]) - 1 : 64 + __ffsll((long long)m_at[NCH - 1]) - 1;
+      if (__popcll(m_at) == 1) {
+        j = __builtin_ctzll(m_at);
       } else {
-        int key = -1;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int k = ((row4col[c] == -1 ? 0x10000 + pos[c] : 0xFFFF - pos[c]) << 1) | c;
-          key = max(key, at_min[c] ? k : -1);
-        }
-        const int best = wave_max_i32<LANES>(key);
-        const int L = __ffsll((long long)__ballot(key == best)) - 1;
-        j = (best & 1) * 64 + L;
+        if (lowest == INFINITY) return 1;
+        // tie: the last unassigned column in list order, else the first one in list order
+        const int k = row4col == -1 ? 0x10000 + pos : 0xFFFF - pos;
+        const int kk = key == lowest ? k : -1;
+        const int best = wave_max_i32<LANES>(kk);
+        j = __builtin_ctzll(__ballot(kk == best));
       }
-      minVal = lowest;
-      const int rj = pick_i32<NCH>(row4col, j);
-      const int pj = pick_i32<NCH>(pos, j);
-      if (rj == -1) sink = j; else i = rj;
+      const int rj = __builtin_amdgcn_readlane(row4col, j);
+      const int pj = __builtin_amdgcn_readlane(pos, j);
       // remove j from the list: the list's last entry moves into j's place
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        pos[c] = pos[c] == num_remaining - 1 ? pj : pos[c];
-        pos[c] = c * 64 + lane == j ? -1 : pos[c];
-      }
-      if (NCH == 1 || j < 64) sc[0] |= 1ull << (j & 63);
-      else sc[NCH - 1] |= 1ull << (j & 63);
       --num_remaining;
-    }
-    // dual updates
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int row = c * 64 + lane;
-      // distance of the column this row is assigned to (gathered from its owner lane)
-      const int cr = col4row[c] < 0 ? 0 : col4row[c];
-      double s_cr = __shfl(spc[0], cr & 63, 64);
-      if constexpr (NCH == 2) {
-        const double s1 = __shfl(spc[1], cr & 63, 64);
-        if (cr >= 64) s_cr = s1;
-      }
-      const bool in_sr = (sr[c] >> lane) & 1ull, in_sc = (sc[c] >> lane) & 1ull;
-      if (row == cur) u[c] += minVal;
-      else if (in_sr) u[c] += minVal - s_cr;
-      if (in_sc) v[c] -= minVal - spc[c];
+      pos = pos == num_remaining ? pj : pos;
+      act &= ~(1ull << j);
+      sc |= 1ull << j;
+      minVal = lowest;
+      if (rj == -1) sink = j; else i = rj;
+    } while (sink == -1);
+    // dual updates: a scanned column's distance is the spc it was removed with
+    {
+      const int cr = col4row < 0 ? 0 : col4row;
+      const double s_cr = __shfl(spc, cr, 64);
+      const bool in_sr = __builtin_amdgcn_inverse_ballot_w64(sr);
+      const bool in_sc = __builtin_amdgcn_inverse_ballot_w64(sc);
+      if (lane == cur) u += minVal;
+      else if (in_sr) u += minVal - s_cr;
+      if (in_sc) v -= minVal - spc;
     }
     // augment along the path (wave-uniform walk)
     int j = sink;
     for (;;) {
-      const int r = pick_i32<NCH>(path, j);
-      const int t = pick_i32<NCH>(col4row, r);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c * 64 + lane == j) row4col[c] = r;
-        if (c * 64 + lane == r) col4row[c] = j;
+      const int r = __builtin_amdgcn_readlane(path, j);
+      const int t = __builtin_amdgcn_readlane(col4row, r);
+      if (lane == j) row4col = r;
+      if (lane == r) col4row = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  return 0;
+}
+
+// The same for 65..128 columns: lane l owns columns (and rows) l and 64 + l; the two halves' sets
+// are two scalar bit masks, a value of column / row k lives in lane k & 63 of half k >> 6 (both
+// halves are read and the scalar unit selects: no branch).
+__device__ __forceinline__ int pick2_i32(int a0, int a1, int k) {
+  const int x0 = __builtin_amdgcn_readlane(a0, k & 63), x1 = __builtin_amdgcn_readlane(a1, k & 63);
+  return k < 64 ? x0 : x1;
+}
+__device__ __forceinline__ double pick2_f64(double a0, double a1, int k) {
+  const double x0 = read_lane_f64(a0, k & 63), x1 = read_lane_f64(a1, k & 63);
+  return k < 64 ? x0 : x1;
+}
+__device__ __forceinline__ int lsap_solve_2(const float *cost, int n, int ld, int lane, int (&col4row)[2]) {
+  double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
+  int path0 = -1, path1 = -1, r4c0 = -1, r4c1 = -1;
+  col4row[0] = col4row[1] = -1;
+  const unsigned long long valid1 = n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull);
+  const float *ccol0 = cost + lane, *ccol1 = cost + min(64 + lane, n - 1);
+  for (int cur = 0; cur < n; ++cur) {
+    double minVal = 0.0, spc0 = INFINITY, spc1 = INFINITY;
+    int i = cur, num_remaining = n, sink = -1;
+    int pos0 = n - 1 - lane, pos1 = n - 65 - lane;
+    unsigned long long act0 = ~0ull, act1 = valid1, sr0 = 0ull, sr1 = 0ull, sc0 = 0ull, sc1 = 0ull;
+    do {
+      const unsigned long long ibit = 1ull << (i & 63);
+      sr0 |= i < 64 ? ibit : 0ull;
+      sr1 |= i < 64 ? 0ull : ibit;
+      const float c0 = ccol0[i * ld], c1 = ccol1[i * ld];
+      const double ui = pick2_f64(u0, u1, i);
+      const double r0 = minVal + (double)(-c0) - ui - v0;
+      const double r1 = minVal + (double)(-c1) - ui - v1;
+      const bool a0 = __builtin_amdgcn_inverse_ballot_w64(act0), a1 = __builtin_amdgcn_inverse_ballot_w64(act1);
+      const bool upd0 = a0 && r0 < spc0, upd1 = a1 && r1 < spc1;
+      spc0 = upd0 ? r0 : spc0; path0 = upd0 ? i : path0;
+      spc1 = upd1 ? r1 : spc1; path1 = upd1 ? i : path1;
+      const double key0 = a0 ? spc0 : INFINITY, key1 = a1 ? spc1 : INFINITY;
+      const double lowest = wave_min_f64<64>(min1_f64(key0, key1));
+      const unsigned long long m0 = __ballot(key0 == lowest), m1 = __ballot(key1 == lowest);
+      int j;
+      if (__popcll(m0) + __popcll(m1) == 1) {
+        j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+      } else {
+        if (lowest == INFINITY) return 1;            // infeasible
+        // tie: the last unassigned column in list order, else the first one in list order
+        const int k0 = ((r4c0 == -1 ? 0x10000 + pos0 : 0xFFFF - pos0) << 1);
+        const int k1 = ((r4c1 == -1 ? 0x10000 + pos1 : 0xFFFF - pos1) << 1) | 1;
+        const int kk = max(key0 == lowest ? k0 : -1, key1 == lowest ? k1 : -1);
+        const int best = wave_max_i32<64>(kk);
+        j = (best & 1) * 64 + __builtin_ctzll(__ballot(kk == best));
       }
+      const int rj = pick2_i32(r4c0, r4c1, j), pj = pick2_i32(pos0, pos1, j);
+      // remove j from the list: the list's last entry moves into j's place
+      --num_remaining;
+      pos0 = pos0 == num_remaining ? pj : pos0;
+      pos1 = pos1 == num_remaining ? pj : pos1;
+      const unsigned long long jbit = 1ull << (j & 63);
+      const unsigned long long jb0 = j < 64 ? jbit : 0ull, jb1 = j < 64 ? 0ull : jbit;
+      act0 &= ~jb0; act1 &= ~jb1;
+      sc0 |= jb0; sc1 |= jb1;
+      minVal = lowest;
+      if (rj == -1) sink = j; else i = rj;
+    } while (sink == -1);
+    // dual updates
+    {
+      const int cr0 = col4row[0] < 0 ? 0 : col4row[0], cr1 = col4row[1] < 0 ? 0 : col4row[1];
+      const double a0 = __shfl(spc0, cr0 & 63, 64), b0 = __shfl(spc1, cr0 & 63, 64);
+      const double a1 = __shfl(spc0, cr1 & 63, 64), b1 = __shfl(spc1, cr1 & 63, 64);
+      const double s_cr0 = cr0 >= 64 ? b0 : a0, s_cr1 = cr1 >= 64 ? b1 : a1;
+      if (lane == cur) u0 += minVal;
+      else if (__builtin_amdgcn_inverse_ballot_w64(sr0)) u0 += minVal - s_cr0;
+      if (64 + lane == cur) u1 += minVal;
+      else if (__builtin_amdgcn_inverse_ballot_w64(sr1)) u1 += minVal - s_cr1;
+      if (__builtin_amdgcn_inverse_ballot_w64(sc0)) v0 -= minVal - spc0;
+      if (__builtin_amdgcn_inverse_ballot_w64(sc1)) v1 -= minVal - spc1;
+    }
+    // augment along the path (wave-uniform walk)
+    int j = sink;
+    for (;;) {
+      const int r = pick2_i32(path0, path1, j);
+      const int t = pick2_i32(col4row[0], col4row[1], r);
+      if (lane == j) r4c0 = r;
+      if (64 + lane == j) r4c1 = r;
+      if (lane == r) col4row[0] = j;
+      if (64 + lane == r) col4row[1] = j;
       j = t;
       if (r == cur) break;
     }
@@ -247,14 +279,14 @@ __device__ __forceinline__ void lsap_wave(const float *cost, int n, int ld, int 
   }
   int fail;
   if (n <= 64) {
-    int col4row[1];
-    if (n <= 16) fail = lsap_solve<1, 16>(cost, n, ld, lane, col4row);
-    else if (n <= 32) fail = lsap_solve<1, 32>(cost, n, ld, lane, col4row);
-    else fail = lsap_solve<1>(cost, n, ld, lane, col4row);
-    if (!fail && lane < n) pg[col4row[0]] = lane;            // perm[col4row[i]] = i
+    int col4row;
+    if (n <= 16) fail = lsap_solve_1<16>(cost, n, ld, lane, col4row);
+    else if (n <= 32) fail = lsap_solve_1<32>(cost, n, ld, lane, col4row);
+    else fail = lsap_solve_1<64>(cost, n, ld, lane, col4row);
+    if (!fail && lane < n) pg[col4row] = lane;               // perm[col4row[i]] = i
   } else {
     int col4row[2];
-    fail = lsap_solve<2>(cost, n, ld, lane, col4row);
+    fail = lsap_solve_2(cost, n, ld, lane, col4row);
     if (!fail) {
       pg[col4row[0]] = lane;
       if (64 + lane < n) pg[col4row[1]] = 64 + lane;
