@@ -252,7 +252,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from graphvae import _hip
-    from graphvae.train.train_ddp import TrainStep
+    from graphvae.train.train_ddp import TrainStep, require_default_priority
 
     def note(msg):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
@@ -273,6 +273,9 @@ def main():
             HostStagedCollectives().broadcast(model.flat_parameters(), src=0)
             note("parameters broadcast")
         # as the trainer runs it: matching half on a second stream, steps pipelined
+        # the step's streams, this one included, must be default-priority streams (event waits
+        # between priority classes have stalled the device): fail before the first step, not in it
+        require_default_priority([torch.cuda.current_stream(device)], "bench.py")
         step_fn = TrainStep(model, 1e-4, 1e-4, 5.0, world, force_collectives=force_dist,
                             pipeline=os.environ.get("GVAE_BENCH_PIPELINE", "1") == "1")
         eng = model._engine_for(batches[0])

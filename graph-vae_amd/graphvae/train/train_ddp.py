@@ -35,6 +35,7 @@ import yaml
 
 from ..data import (DenseGraphBatch, DenseLoader, GraphData, collate, graph_from_adjacency,
                     graph_from_networkx, synthetic_adjacencies)
+from .. import _hip
 from ..engine import MATCH_STREAM, PHASE_ASSIGN_LOSS, PHASE_MATCH, PHASE_MPM, PHASE_PREP, PHASE_TAIL
 from ..models.model import GraphVAE
 
@@ -240,6 +241,22 @@ def concurrent_stream(device, others=(), tries: int = 4) -> "torch.cuda.Stream":
     return chosen
 
 
+def require_default_priority(streams, what: str) -> None:
+    """Raises if any of the streams (None entries are skipped) is not a default-priority stream.
+    The step exchanges event waits between its streams while kernels of several of them are in
+    flight; twice on MI355X such waits between a high-priority and a default-priority stream
+    ended with the device no longer retiring the default-priority stream's work (a side stream
+    created with priority -1, and c10d's gloo path, which stages device tensors on a
+    high-priority pool stream), although the event graph had no cycle.  Every stream of a step,
+    the caller's current one included, therefore has to be of the default priority class."""
+    for st in streams:
+        if st is not None and getattr(st, "priority", 0) != 0:
+            raise _hip.GvaeHipError(
+                f"{what}: stream {st} has priority {st.priority}; the step's streams (the current one "
+                "included) must all have default priority -- event waits between priority classes "
+                "have stalled the device")
+
+
 class TrainStep:
     """forward + backward + gradient all-reduce + clip + Adam, all on flat buffers.
     loss = rec + beta * kl (reference train_ddp.py:282-292,316)."""
@@ -288,11 +305,11 @@ class TrainStep:
         self._side = None       # second stream + events, created on first use
         self._tail = None       # pipelined: third stream for assignment + losses
         self._fourth = None     # pipelined: the S-free tail of a streamed matching / every other assignment
-        self._assign_flip = False
+        self._rot = 0
         self._ev_acc_last = self._acc_stream_last = None
         self._ev_model = self._ev_match = self._ev_mpm = self._ev_tail = self._ev_tail_last = None
         self._slot = 0
-        self.n_slots = max(2, int(slots if slots is not None else os.environ.get("GVAE_PIPELINE_SLOTS", "3")))
+        self.n_slots = max(2, int(slots if slots is not None else os.environ.get("GVAE_PIPELINE_SLOTS", "4")))
         # sum over the steps since the last pop_loss_sum() of rec + beta * kl, accumulated where
         # the losses are produced (on the side stream when the matching is overlapped)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=flat.device)
@@ -355,6 +372,9 @@ class TrainStep:
             eps = torch.randn(batch.num_graphs, model.z_dim, dtype=torch.float32, device=batch.device)
         overlap = self.overlap_matching and hasattr(eng, "forward_match_loss")
         if overlap:
+            main = torch.cuda.current_stream(self.grads.device)
+            # event waits between priority classes stalled the device (see concurrent_stream)
+            require_default_priority([main], "TrainStep")
             if self._side is None:
                 self._side = concurrent_stream(self.grads.device, tries=self.probe_tries)
                 self._ev_model = [torch.cuda.Event() for _ in range(self.n_slots)]
@@ -369,10 +389,7 @@ class TrainStep:
                                                    tries=self.probe_tries)
                     self._fourth = concurrent_stream(self.grads.device, others=[self._side, self._tail],
                                                      tries=self.probe_tries)
-                for st in (self._side, self._tail, self._fourth):
-                    # event waits between priority classes stalled the device (see concurrent_stream)
-                    assert st is None or st.priority == 0, "side streams must have default priority"
-            main = torch.cuda.current_stream(self.grads.device)
+                require_default_priority([self._side, self._tail, self._fourth], "TrainStep")
             k = self._slot
             if self.pipeline:
                 eng.use_slot(k)
@@ -387,25 +404,26 @@ class TrainStep:
                 # (streams are passed to the engine; a stream context costs the host more than
                 # the launches it would wrap)
                 side, tail = self._side, self._tail
-                side.wait_event(self._ev_model[k])
                 if tail is None:
+                    side.wait_event(self._ev_model[k])
                     res, last = eng.forward_match_loss(stream=side), side
                 elif getattr(eng, "last_mode", None) != MATCH_STREAM:
-                    # S-free matching: the assignments of consecutive steps (one wavefront per
-                    # graph: 0.18 ms at 32 nodes, 1.5 ms at 80, whatever the batch) alternate
-                    # between two streams, so that two of them run side by side
-                    if self._assign_flip:
-                        tail = self._fourth
-                    self._assign_flip = not self._assign_flip
-                    eng.forward_match_loss(PHASE_MATCH, stream=side)
-                    self._ev_mpm[k].record(side)
-                    tail.wait_event(self._ev_mpm[k])
-                    res, last = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=tail), tail
+                    # S-free matching: MPM, assignment (the epilogue of a graph's work-group, as
+                    # soon as that graph has converged) and losses of a step are one chain, and the
+                    # chains of consecutive steps rotate over the three side streams.  Both kernels
+                    # are latency-bound (a work-group, then a wavefront, per graph: 0.17 + 0.15 ms
+                    # at 32 nodes, 0.55 + 1.1 ms on ENZYMES-shaped batches, whatever the batch
+                    # size), so three of them side by side cost a step a third of the chain.
+                    last = (side, tail, self._fourth)[self._rot]
+                    self._rot = (self._rot + 1) % 3
+                    last.wait_event(self._ev_model[k])
+                    res = eng.forward_match_loss(PHASE_MATCH | PHASE_ASSIGN_LOSS, stream=last)
                 else:
                     # Streamed matching: the similarity tensor of this step is written while the
                     # S-free tail of the previous step (a work-group per surviving graph, on a
                     # stream of its own) still runs; the persistent launch waits for that tail, which
                     # would find no room beside it
+                    side.wait_event(self._ev_model[k])
                     eng.forward_match_loss(PHASE_PREP, stream=side)
                     if self._ev_tail_last is not None:
                         side.wait_event(self._ev_tail_last)

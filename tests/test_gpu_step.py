@@ -532,3 +532,29 @@ def test_accumulate_loss_entry_point():
     assert torch.equal(copy, out4)
     eng.accumulate_loss(out4, beta, acc)                  # the copy is optional
     assert acc.item() == 1.5 + step + step + step
+
+
+@pytest.mark.gpu
+def test_step_refuses_high_priority_streams():
+    """TrainStep with its matching on side streams refuses to run when the caller's current
+    stream is a high-priority one (the guard bench.py applies too): the error comes before any
+    kernel of the step is enqueued."""
+    from graphvae import _hip
+    from graphvae.data import synthetic_batch
+    from graphvae.models import GraphVAE
+    from graphvae.train.train_ddp import TrainStep
+    N, B = 16, 8
+    hb = synthetic_batch("enzymes", B, N, "deg", seed=5)
+    torch.manual_seed(1)
+    model = GraphVAE(1, 32, 16, N).to(DEV)
+    model.precompute_dataset_rho([hb])
+    model.train()
+    step = TrainStep(model, 1e-3, 0.0, 5.0, pipeline=True)
+    high = torch.cuda.Stream(device=DEV, priority=-1)
+    with torch.cuda.stream(high):
+        with pytest.raises(_hip.GvaeHipError, match="default priority"):
+            step(hb.to(DEV), 0.5, 1.0)
+    torch.cuda.synchronize()
+    out = step(hb.to(DEV), 0.5, 1.0)          # the same object runs from a default-priority stream
+    step.wait()
+    assert torch.isfinite(out).all()

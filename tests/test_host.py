@@ -248,3 +248,15 @@ def test_s_chunks_cover_the_batch_within_budget():
     assert _hip.s_chunks(Rh, 10 ** 12)[0] == [0, len(Rh)]
     with pytest.raises(_hip.GvaeHipError):
         _hip.s_chunks(Rh, blk[1] - 4)
+
+
+def test_priority_guard_rejects_non_default_streams():
+    """Streams of a step must all be default-priority streams (train_ddp.require_default_priority):
+    None entries are skipped, a stream of another priority class raises before any step runs."""
+    from types import SimpleNamespace
+    from graphvae import _hip
+    from graphvae.train.train_ddp import require_default_priority
+    ok = SimpleNamespace(priority=0)
+    require_default_priority([ok, None, ok], "test")
+    with pytest.raises(_hip.GvaeHipError, match="default priority"):
+        require_default_priority([ok, SimpleNamespace(priority=-1)], "test")
