@@ -44,7 +44,8 @@ p = ROOT / "profiles" / "pmc_traffic.json"
 allv = json.load(open(p)) if p.exists() else {}
 allv[key] = entry
 json.dump(allv, open(p, "w"), indent=1)
-out = ROOT / "profiles" / f"r2_pmc_matching_{key}.csv"
+import os
+out = ROOT / "profiles" / f"{os.environ.get('GVAE_PMC_ROUND', 'r2')}_pmc_matching_{key}.csv"
 with open(out, "w", newline="") as fo:
     w = csv.writer(fo)
     w.writerow(["pass", "kernel", "grid", "workgroup", "counter", "value_KB", "duration_us"])

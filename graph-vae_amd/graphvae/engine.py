@@ -189,7 +189,8 @@ class StepEngine:
     def _ensure(self, B: int) -> None:
         if self._ws is None or B > self._ws_graphs:
             need = self.L.gvae_step_ws_bytes(ctypes.byref(self.dims), B)
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # (zeroed once: the streamed matching's statistics words in it are only ever added to)
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
             self._ws_graphs = B
         if self.perm is None or self.perm.shape[0] != B:
             self.perm = torch.empty(B, self.N, dtype=torch.int64, device=self.device)

@@ -306,6 +306,7 @@ class TrainStep:
         self._tail = None       # pipelined: third stream for assignment + losses
         self._fourth = None     # pipelined: the S-free tail of a streamed matching / every other assignment
         self._rot = 0
+        self.fuse_assignment = True   # S-free pipelined steps: the assignment as the MPM kernel's epilogue
         self._ev_acc_last = self._acc_stream_last = None
         self._ev_model = self._ev_match = self._ev_mpm = self._ev_tail = self._ev_tail_last = None
         self._slot = 0
@@ -417,7 +418,11 @@ class TrainStep:
                     last = (side, tail, self._fourth)[self._rot]
                     self._rot = (self._rot + 1) % 3
                     last.wait_event(self._ev_model[k])
-                    res = eng.forward_match_loss(PHASE_MATCH | PHASE_ASSIGN_LOSS, stream=last)
+                    if self.fuse_assignment:
+                        res = eng.forward_match_loss(PHASE_MATCH | PHASE_ASSIGN_LOSS, stream=last)
+                    else:       # (the MPM kernel and the assignment as two launches: to time them apart)
+                        eng.forward_match_loss(PHASE_MATCH, stream=last)
+                        res = eng.forward_match_loss(PHASE_ASSIGN_LOSS, stream=last)
                 else:
                     # Streamed matching: the similarity tensor of this step is written while the
                     # S-free tail of the previous step (a work-group per surviving graph, on a
