@@ -185,7 +185,7 @@ int gvae_lsap(const float *d_X, int ldx, int64_t strideX, const int32_t *d_R, in
 
 /* gvae_mpm_fused followed by gvae_lsap (graphvae/models/model.py:317-323: the MPM and the
  * assignment on its result).  While every graph's work-group fits on the device at once (1024 /
- * 512 / 256 graphs for r_max <= 32 / 64 / 115) this is ONE launch: the work-group that iterated
+ * 512 / 256 graphs for r_max <= 32 / 64 / 128) this is ONE launch: the work-group that iterated
  * a graph solves that graph's assignment from the X it holds in LDS, so a graph that converges
  * early is assigned early instead of waiting for the slowest graph of the batch; larger batches
  * run as the two launches.  Same X, same perm, same status either way. */
