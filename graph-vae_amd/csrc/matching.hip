@@ -573,29 +573,6 @@ __host__ __device__ __forceinline__ int mpm_slab_kb(int R, int RS) {
   return (int)(((long long)R * R * R * RS * 4 + 1023) >> 10);
 }
 
-// Diagnostic build (-DGVAE_STREAM_STAMPS): lane 0 of a few work-groups prints the cycles its
-// items spent per phase.
-#ifdef GVAE_STREAM_STAMPS
-#define SSTAMP(k) do { if (tid == 0) { const long long t_ = __builtin_readcyclecounter(); \
-                       ss_acc[k] += t_ - ss_last; ss_last = t_; } } while (0)
-#else
-#define SSTAMP(k) do {} while (0)
-#endif
-
-// Diagnostic build (-DGVAE_STREAM_TRACE): every item leaves one 64-byte record of 100 MHz
-// wall-clock stamps in a caller-supplied buffer (gvae_debug_trace):
-//   [0] item word | block << 32   [1] ticket drawn  [2] item received  [3] X loaded
-//   [4] rows streamed and stored  [5] arrival counted  [6] last arriver: next items pushed (else 0)
-//   [7] graph iteration's item count << 32 | rows of this item
-#ifdef GVAE_STREAM_TRACE
-__device__ unsigned long long *g_trace_buf;
-__device__ unsigned g_trace_cap;
-__device__ unsigned g_trace_n;
-#define TSTAMP(k) do { if (tid == 0) tr[k] = wall_clock64(); } while (0)
-#else
-#define TSTAMP(k) do {} while (0)
-#endif
-
 __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAVES))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
@@ -613,20 +590,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       &s_nb = ctl[5], &s_done = ctl[6], &s_alive = ctl[7], &s_alive_kb = ctl[8];
   float *lds = lds_all + kCtlFloats;
   const int tid = threadIdx.x, nt = blockDim.x;
-#ifdef GVAE_STREAM_STAMPS
-  long long ss_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long ss_last = __builtin_readcyclecounter();
-  int ss_items = 0, ss_lasts = 0;
-#endif
-#ifdef GVAE_STREAM_TRACE
-  unsigned long long tr[8];
-#endif
   for (;;) {
-    SSTAMP(9);
-#ifdef GVAE_STREAM_TRACE
-    for (int k = 0; k < 8; ++k) tr[k] = 0;
-#endif
-    TSTAMP(1);
     // ---- draw a ticket and wait for its granule (one lane)
     if (tid == 0) {
       const unsigned ticket = (unsigned)__hip_atomic_fetch_add(Q_HEAD(q), 1, __ATOMIC_RELAXED,
@@ -671,11 +635,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
     // registers (addresses, loop bounds)
     const int item = __builtin_amdgcn_readfirstlane(s_item);
     if (item == -2) break;
-    SSTAMP(0);
-    TSTAMP(2);
-#ifdef GVAE_STREAM_STAMPS
-    ++ss_items;
-#endif
     if ((unsigned)item != MPM_NULL_ITEM) {
       const int g = (unsigned)item >> 16, i0 = (item >> 8) & 0xFF, q_blk = (item >> 4) & 0xF;
       const int shape = item & 0xF;
@@ -730,12 +689,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         s_alive_kb = alive_kb_r;
       }
       __syncthreads();
-      TSTAMP(3);
       for (int ri = 0; ri < rows_here; ++ri) {
         const int i = i0 + ri;
         const float *slab = Sg + (int64_t)i * R2 * RS;
         const float *nsr = nsrow + ri * R;
-        SSTAMP(1);
         if ((RS & 3) == 0) {
           if (q.two_buffers) mpm_iter_dispatch<4, true>(slab, R, RS, a0, Aw, Xs, T);
           else mpm_iter_dispatch<4>(slab, R, RS, a0, Aw, Xs, T, q.wide_rows);
@@ -743,7 +700,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         else if ((RS & 1) == 0) mpm_iter_dispatch<2>(slab, R, RS, a0, Aw, Xs, T);
         else mpm_iter_dispatch<1>(slab, R, RS, a0, Aw, Xs, T);
         __syncthreads();
-        SSTAMP(2);
         for (int p = a0 + tid; p < a0 + Aw; p += nt) {
           // the row j == i does not take part in the sum: an exact +0 at its position
           const float et = column_sum(
@@ -757,20 +713,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       // publish this row: every storing wave drains its stores, then one lane takes a ticket
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      SSTAMP(3);
-      TSTAMP(4);
       if (tid == 0) {
         const int before = __hip_atomic_fetch_add(&q.arrive[g], rows_here, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
         s_last = (before + rows_here == R * n_blk) ? 1 : 0;
       }
       __syncthreads();
-      SSTAMP(4);
-      TSTAMP(5);
       if (s_last) {
-#ifdef GVAE_STREAM_STAMPS
-        ++ss_lasts;
-#endif
         // ---- last arriver: normalise the graph
         // (the other producers' rows: write-through stores, read past the vector cache)
         for (int e0 = tid; e0 < R2; e0 += 4 * nt) {
@@ -784,7 +733,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
             if (e0 + u * nt < R2) T[e0 + u * nt] = v[u];
         }
         __syncthreads();
-        SSTAMP(5);
         const int n8 = R2 & ~7;
         if (tid < 64) {
           float acc = 0.f;
@@ -793,7 +741,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
           if (tid == 0) s_nrm = nrm;
         }
         __syncthreads();
-        SSTAMP(6);
         const float nrm = s_nrm;
         float dmax = 0.f;
         bool isnan_any = false;
@@ -848,7 +795,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         // X, the iteration count and the reset counter are drained before anything is pushed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        SSTAMP(7);
         if (s_cont) {
           const unsigned base = (unsigned)s_base;
           const int shape_next = s_nb, n_next = mpm_shape_items(R, shape_next);
@@ -874,29 +820,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
         } else if (tid == 0) {
           __hip_atomic_fetch_add(Q_REMAIN(q), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        TSTAMP(6);
       }
-#ifdef GVAE_STREAM_TRACE
-      if (tid == 0) {
-        const unsigned n = atomicAdd(&g_trace_n, 1u);
-        if (n < g_trace_cap) {
-          tr[0] = (unsigned)item | ((unsigned long long)blockIdx.x << 32);
-          tr[7] = ((unsigned long long)(R * n_blk) << 32) | (unsigned)rows_here;
-          for (int k = 0; k < 8; ++k) g_trace_buf[8ull * n + k] = tr[k];
-        }
-      }
-#endif
     }
     __syncthreads();  // s_item and the LDS buffers are free again
-    SSTAMP(8);
   }
-#ifdef GVAE_STREAM_STAMPS
-  if (tid == 0 && ss_items > 0 && (blockIdx.x & 255) == 0)
-    printf("stream stamps wg %d: items %d lasts %d | wait %lld  xload %lld  stream %lld  colsum+store %lld  "
-           "arrive %lld | last: reload %lld  norm %lld  divide+store %lld  push %lld | loop %lld\n",
-           blockIdx.x, ss_items, ss_lasts, ss_acc[0], ss_acc[1], ss_acc[2], ss_acc[3], ss_acc[4],
-           ss_acc[5], ss_acc[6], ss_acc[7], ss_acc[8], ss_acc[9]);
-#endif
 }
 
 // first generation of the ring, compact: the items of graph g start at the sum of the item
@@ -1357,13 +1284,6 @@ __global__ __launch_bounds__(256) void mpm_second_norm_kernel(
 // The previous X lives in the caller's d_X buffer (global), the new one in LDS.
 // ---------------------------------------------------------------------------
 
-// Diagnostic build (-DGVAE_FUSED_STAMPS): work-group 0 prints the cycles it spent per phase.
-#ifdef GVAE_FUSED_STAMPS
-#define STAMP(k) do { __syncthreads(); const long long t_ = __builtin_readcyclecounter(); \
-                      st_acc[k] += t_ - st_last; st_last = t_; } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
 
 // Canonical column sums of NCH rows that share one column a: chain c adds, for j = 0..R-1 in the
 // canonical order, M[j,a] if j is a neighbour of row c and an exact +0 otherwise.  The M values
@@ -1686,18 +1606,10 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
   while (split_log2 < 2 && ((R * JQ) << (split_log2 + 1)) <= nt) ++split_log2;
   int done = resume != nullptr ? iters_done[g] : 0;
   int par = 0;
-#ifdef GVAE_FUSED_STAMPS
-  long long st_acc[5] = {0, 0, 0, 0, 0}, st_inner = 0;
-  long long st_last = __builtin_readcyclecounter();
-#endif
   for (int it = done; it < iters; ++it) {
-    STAMP(4);
     // phase 1: M[j,a] = max_b Pp[a,b] * X[j,b]  (>= 0; Pp[a,a] = 0).  A lane takes one column a
     // and four consecutive rows j at a time: per 4 values of b it reads one 16-byte piece of
     // Pp's row a and four (wave-broadcast) pieces of X; products in pairs (packed multiply).
-#ifdef GVAE_FUSED_STAMPS
-    const long long ti0 = __builtin_readcyclecounter();
-#endif
     auto phase1 = [&](auto sl_tag) {
       constexpr int SL = decltype(sl_tag)::value;
       const int part = tid & ((1 << SL) - 1);
@@ -1742,11 +1654,7 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       phase1(std::integral_constant<int, 1>{});
     else
       phase1(std::integral_constant<int, 2>{});
-#ifdef GVAE_FUSED_STAMPS
-    st_inner += __builtin_readcyclecounter() - ti0;
-#endif
     __syncthreads();
-    STAMP(0);
     // phase 2: Xn[i,a] = Xprev[i,a]*NS[i,a] + sum_{j: A[i,j]} M[j,a]  (canonical column sums),
     // kept in registers until every lane has read M, then stored in the norm's layout over M
     // (KMAX > 4: in X's own words instead, each rewritten by its owner only)
@@ -1794,7 +1702,6 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       }
     }
     __syncthreads();
-    STAMP(1);
     // phase 3: canonical norm over the R*R elements in flat order
     if (tid < 64) {
       float acc = 0.f;
@@ -1803,7 +1710,6 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       if (tid == 0) s_nrm = nrm;
     }
     __syncthreads();
-    STAMP(2);
     const float nrm = s_nrm;
     float dmax = 0.f;
     bool isnan_any = false;
@@ -1833,15 +1739,9 @@ __global__ __launch_bounds__(NT, 4) void mpm_fused_kernel(
       d = fmaxf(fmaxf(d, fmaxf(r4.x, r4.y)), fmaxf(r4.z, r4.w));
     }
     par ^= 1;
-    STAMP(3);
     ++done;
     if (early_stop && d < tol) break;
   }
-#ifdef GVAE_FUSED_STAMPS
-  if (g == 0 && tid == 0)
-    printf("fused stamps R=%d iters=%d: maxprod %lld (lane 0 without the barrier %lld)  colsum %lld  norm %lld  divide+test %lld  loop %lld cycles\n",
-           R, done, st_acc[0], st_inner, st_acc[1], st_acc[2], st_acc[3], st_acc[4]);
-#endif
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const int i = tj + k * TJ;
@@ -2124,22 +2024,6 @@ using namespace gvae;
 
 extern "C" {
 
-#ifdef GVAE_STREAM_TRACE
-// diagnostic builds only: where the streamed MPM leaves its per-item records (cap records of 64 bytes)
-int gvae_debug_trace(void *d_buf, int cap) {
-  unsigned zero = 0, ucap = (unsigned)cap;
-  unsigned long long *b = (unsigned long long *)d_buf;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)) != hipSuccess) return GVAE_ELAUNCH;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &ucap, sizeof(ucap)) != hipSuccess) return GVAE_ELAUNCH;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero)) != hipSuccess) return GVAE_ELAUNCH;
-  return GVAE_OK;
-}
-int gvae_debug_trace_count(void) {
-  unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -1;
-  return (int)n;
-}
-#endif
 
 int gvae_node_sim(const float *d_A, const float *d_P, const int32_t *d_R, int n_graphs, int ld,
                   int64_t stride, float *d_NS, void *stream) {
@@ -2320,15 +2204,6 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // up to 126): 0.877 against 0.89 of HBM peak, no change on the ragged batch -- off
   q.two_buffers = 0;
   q.wide_rows = 1;
-#ifdef GVAE_TUNE
-  // tuning builds only: launch shape and item-shape thresholds from the environment
-  if (const char *e = getenv("GVAE_MPM_NT")) nt = atoi(e);
-  if (const char *e = getenv("GVAE_MPM_LOW")) q.low = atoi(e);
-  if (const char *e = getenv("GVAE_MPM_HIGH")) q.high = atoi(e);
-  if (const char *e = getenv("GVAE_MPM_TWO")) q.two_buffers = atoi(e);
-  if (const char *e = getenv("GVAE_MPM_CAP")) q.item_cap_kb = atoi(e);
-  if (const char *e = getenv("GVAE_MPM_WIDE")) q.wide_rows = atoi(e);
-#endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)mpm_stream_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2342,9 +2217,6 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // take is what lets kernels of other streams (the backward's GEMMs, 128 registers) run beside
   // this persistent kernel instead of queueing until it ends.
   int max_blocks = nt == 256 ? 1024 : 2048 * 256 / nt;
-#ifdef GVAE_TUNE
-  if (const char *e = getenv("GVAE_MPM_BLOCKS")) max_blocks = atoi(e);
-#endif
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
                      s_layout, d_iters_done, first_stop, iters);
