@@ -233,141 +233,19 @@ int launch_gemm_group(GemmDesc *descs, int n, float *splitk_base, int64_t splitk
 }
 
 // ---------------------------------------------------------------------------
-// Ahat = D^-1/2 (A + I) D^-1/2 over the first n_x rows/cols of each graph; the
-// dense adjacency already carries a unit diagonal on the R real nodes, rows in
-// [R, n_x) are isolated feature rows with only their self loop.
+// Per-graph BatchNorm1d (eps 1e-5) + ReLU over the graph's n_x live rows: running statistics and
+// the backward (one work-group per (graph, 64-column slab), 4 row lanes per column); the forward
+// is a stage of the model kernels further down.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void gcn_norm_adj_body(const float *__restrict__ adj,
-                                                  const int32_t *__restrict__ n_x,
-                                                  const int32_t *__restrict__ Rarr, int N,
-                                                  float *__restrict__ Ahat, int g) {
-  __shared__ float dinv[1024];
-  const int tid = threadIdx.x;
-  const int nx = n_x[g], R = Rarr[g];
-  const float *Ag = adj + (int64_t)g * N * N;
-  float *Og = Ahat + (int64_t)g * N * N;
-  for (int i = tid; i < N; i += 256) {
-    float deg = 1.0f;  // self loop
-    if (i < R)
-      for (int j = 0; j < R; ++j)
-        if (j != i) deg += (Ag[(int64_t)i * N + j] != 0.0f) ? 1.0f : 0.0f;
-    dinv[i] = (i < nx) ? 1.0f / sqrtf(deg) : 0.0f;
-  }
-  __syncthreads();
-  for (int e = tid; e < N * N; e += 256) {
-    const int i = e / N, j = e - i * N;
-    float a = 0.0f;
-    if (i < nx && j < nx) {
-      if (i == j) a = 1.0f;
-      else if (i < R && j < R) a = (Ag[e] != 0.0f) ? 1.0f : 0.0f;
-    }
-    Og[e] = dinv[i] * a * dinv[j];
-  }
-}
 
-__global__ __launch_bounds__(256) void gcn_norm_adj_kernel(const float *__restrict__ adj,
-                                                           const int32_t *__restrict__ n_x,
-                                                           const int32_t *__restrict__ Rarr, int N,
-                                                           float *__restrict__ Ahat) {
-  gcn_norm_adj_body(adj, n_x, Rarr, N, Ahat, blockIdx.x);
-}
-
-int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
-                        float *Ahat, hipStream_t s) {
-  GVAE_REQUIRE(N <= 1024, GVAE_ELIMIT, "gcn_norm_adj: N=%d > 1024", N);
-  hipLaunchKernelGGL(gcn_norm_adj_kernel, dim3(B), dim3(256), 0, s, adj, n_x, R, N, Ahat);
-  return check_launch("gcn_norm_adj");
-}
-
-// ---------------------------------------------------------------------------
-// Per-graph BatchNorm1d (eps 1e-5) + ReLU over the graph's n_x live rows.
-// One work-group per (graph, 64-column slab); 4 row lanes per column.
-// ---------------------------------------------------------------------------
-#define BN_EPS 1e-5f
-
-// Column statistics are accumulated in double, as PyTorch's CPU BatchNorm does
-// (its accumulation type for float is double), then rounded to fp32 once.
+// Column sums are accumulated in double (as PyTorch's CPU BatchNorm does: its accumulation type
+// for float is double) by four row lanes per column and folded in a fixed order.
 __device__ __forceinline__ double quad_rows_sum(double v, double (*sh)[64], int rl, int c) {
   sh[rl][c] = v;
   __syncthreads();
   const double t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
   __syncthreads();
   return t;
-}
-
-__device__ __forceinline__ void bn_relu_fwd_body(
-    float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
-    const float *__restrict__ beta, const float *__restrict__ run_mean,
-    const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
-    float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
-    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o, int g, int slab) {
-  __shared__ double sh[4][64];
-  const int tid = threadIdx.x;
-  const int cl = tid & 63, rl = tid >> 6, c = slab * 64 + cl;
-  const bool cv = c < H;
-  const int nx = n_x[g];
-  // which statistics this forward normalised with: the backward of the batch reads it
-  if (mode_o && g == 0 && slab == 0 && tid == 0) mode_o[0] = train;
-  float *Yg = Y + (int64_t)g * N * H;
-  float *Og = out + (int64_t)g * N * H;
-  const float b = cv ? bias[c] : 0.0f;
-  float mean, invstd;
-  if (train) {
-    double s = 0.0;
-    if (cv) for (int i = rl; i < nx; i += 4) s += (double)(Yg[(int64_t)i * H + c] + b);
-    s = quad_rows_sum(s, sh, rl, cl);
-    const double mean_d = s / (double)nx;
-    double q = 0.0;
-    if (cv) for (int i = rl; i < nx; i += 4) {
-      const double dlt = (double)(Yg[(int64_t)i * H + c] + b) - mean_d;
-      q += dlt * dlt;
-    }
-    q = quad_rows_sum(q, sh, rl, cl);
-    mean = (float)mean_d;
-    invstd = (float)(1.0 / sqrt(q / (double)nx + (double)BN_EPS));
-    if (cv && rl == 0) {
-      mean_o[(int64_t)g * H + c] = mean;
-      invstd_o[(int64_t)g * H + c] = invstd;
-      var_unb_o[(int64_t)g * H + c] = (float)(q / (double)(nx - 1));
-    }
-  } else {
-    mean = cv ? run_mean[c] : 0.0f;
-    invstd = cv ? 1.0f / sqrtf(run_var[c] + BN_EPS) : 0.0f;
-    if (cv && rl == 0) {
-      mean_o[(int64_t)g * H + c] = mean;
-      invstd_o[(int64_t)g * H + c] = invstd;
-    }
-  }
-  if (!cv) return;
-  const float ga = gamma[c], be = beta[c];
-  for (int i = rl; i < N; i += 4) {
-    float o = 0.0f, xc = 0.0f;
-    if (i < nx) {
-      xc = (Yg[(int64_t)i * H + c] + b) - mean;
-      o = fmaxf(xc * invstd * ga + be, 0.0f);
-    }
-    Og[(int64_t)i * H + c] = o;
-    Yg[(int64_t)i * H + c] = xc;      // the backward reads the centred value
-  }
-}
-
-__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(
-    float *__restrict__ Y, const float *__restrict__ bias, const float *__restrict__ gamma,
-    const float *__restrict__ beta, const float *__restrict__ run_mean,
-    const float *__restrict__ run_var, const int32_t *__restrict__ n_x, int N, int H, int train,
-    float *__restrict__ out, float *__restrict__ mean_o, float *__restrict__ invstd_o,
-    float *__restrict__ var_unb_o, int32_t *__restrict__ mode_o) {
-  bn_relu_fwd_body(Y, bias, gamma, beta, run_mean, run_var, n_x, N, H, train, out, mean_o, invstd_o,
-                   var_unb_o, mode_o, blockIdx.y, blockIdx.x);
-}
-
-int launch_bn_relu_fwd(float *Y, const float *bias, const float *gamma, const float *beta,
-                       const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
-                       int H, int train, float *out, float *mean, float *invstd, float *var_unb,
-                       int32_t *mode_out, hipStream_t s) {
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, Y, bias, gamma,
-                     beta, run_mean, run_var, n_x, N, H, train, out, mean, invstd, var_unb, mode_out);
-  return check_launch("bn_relu_fwd");
 }
 
 // The reference applies BatchNorm graph by graph (model.py:295-296), i.e. B sequential
@@ -541,37 +419,6 @@ int launch_colsum(const float *M, int rows, int cols, int64_t ld, float *out, in
   return check_launch("colsum");
 }
 
-// pooled graph vector: sum over the n_x live rows divided by the real node count
-// (reference model.py:141-142,297)
-__device__ __forceinline__ void pool_fwd_body(const float *__restrict__ Hm,
-                                              const int32_t *__restrict__ n_x,
-                                              const int32_t *__restrict__ Rarr, int N, int H,
-                                              float *__restrict__ gvec, int g, int slab) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = slab * 64 + cl;
-  const int nx = n_x[g];
-  float s = 0.0f;
-  if (c < H) for (int i = rl; i < nx; i += 4) s += Hm[((int64_t)g * N + i) * H + c];
-  sh[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && c < H)
-    gvec[(int64_t)g * H + c] = ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) / (float)Rarr[g];
-}
-
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Hm,
-                                                       const int32_t *__restrict__ n_x,
-                                                       const int32_t *__restrict__ Rarr, int N, int H,
-                                                       float *__restrict__ gvec) {
-  pool_fwd_body(Hm, n_x, Rarr, N, H, gvec, blockIdx.y, blockIdx.x);
-}
-
-int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
-                    float *gvec, hipStream_t s) {
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ceil_div(H, 64), B), dim3(256), 0, s, Hm, n_x, R, N, H,
-                     gvec);
-  return check_launch("pool_fwd");
-}
-
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float *__restrict__ dgvec,
                                                        const int32_t *__restrict__ n_x,
                                                        const int32_t *__restrict__ Rarr, int N, int H,
@@ -590,23 +437,6 @@ int launch_pool_bwd(const float *dgvec, const int32_t *n_x, const int32_t *R, in
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(min(ceil_div(N * H, 256), 64), B), dim3(256), 0, s, dgvec,
                      n_x, R, N, H, dH);
   return check_launch("pool_bwd");
-}
-
-// z = mu + eps * exp(0.5 * clamp(lvraw, -4, 4))   (reference model.py:298-299,137-139)
-__global__ void reparam_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ lvraw,
-                                   const float *__restrict__ eps, int n, float *__restrict__ z) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const float lv = fminf(fmaxf(lvraw[e], -4.0f), 4.0f);
-  z[e] = mu[e] + eps[e] * expf(0.5f * lv);
-}
-
-int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, int B, int Z, float *z,
-                       hipStream_t s) {
-  const int n = B * Z;
-  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, mu, lvraw, eps, n,
-                     z);
-  return check_launch("reparam_fwd");
 }
 
 // ---------------------------------------------------------------------------
@@ -796,7 +626,7 @@ __device__ __forceinline__ void tile64_foreach(const Acc64 &acc, int m0, int n0,
 }
 
 // BatchNorm + ReLU of buf + bias in place (doubles in LDS), a 64-column slab per 256 threads, 4
-// row lanes per column as in bn_relu_fwd_body; fp32 copies for the backward: the activation
+// row lanes per column (quad_rows_sum); fp32 copies for the backward: the activation
 // (out) and the centred pre-activation (yc)
 template <int NT>
 __device__ __forceinline__ void bn_relu_lds64(double *buf, int hs, int NP, int N, int H, int nx,
@@ -1417,16 +1247,6 @@ int launch_reparam_bwd(const float *dz, const float *mu, const float *lvraw, con
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, dz, mu, lvraw, eps,
                      n, Z, c_kl / (float)B, d_up, dmu, dlvraw);
   return check_launch("reparam_bwd");
-}
-
-__global__ void relu_mask_kernel(float *__restrict__ dX, const float *__restrict__ act, int64_t n) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n && !(act[e] > 0.0f)) dX[e] = 0.0f;
-}
-
-int launch_relu_mask(float *dX, const float *act, int64_t n, hipStream_t s) {
-  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dX, act, n);
-  return check_launch("relu_mask");
 }
 
 // index of pair (a,b), a < b, in row-major upper-triangle order (torch.triu_indices(N,N,1))

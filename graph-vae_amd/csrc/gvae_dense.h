@@ -80,15 +80,6 @@ struct ModelBwdArgs {
 };
 int launch_model_bwd_graph(const ModelBwdArgs &a, int B, hipStream_t s);
 
-int launch_gcn_norm_adj(const float *adj, const int32_t *n_x, const int32_t *R, int B, int N,
-                        float *Ahat, hipStream_t s);
-// BatchNorm over each graph's n_x live rows + ReLU.  train != 0: batch statistics
-// (written to mean / invstd / var_unbiased, each (B,H)); else running statistics.
-// mode_out (device, nullable) receives `train`: launch_bn_relu_bwd of the same batch reads it.
-int launch_bn_relu_fwd(float *Y, const float *bias, const float *gamma, const float *beta,
-                       const float *run_mean, const float *run_var, const int32_t *n_x, int B, int N,
-                       int H, int train, float *out, float *mean, float *invstd, float *var_unb,
-                       int32_t *mode_out, hipStream_t s);
 // running statistics of up to two BatchNorm layers after a training forward, in one launch
 struct BnRunningArgs {
   const float *mean[2], *var_unb[2];
@@ -97,8 +88,10 @@ struct BnRunningArgs {
   float momentum;
 };
 int launch_bn_running_update(const BnRunningArgs &a, hipStream_t s);
-// dY (B,N,H) from dOut; per-graph partial sums dgamma_p, dbeta_p, dbias_p (B,H).  mode (device):
-// non-zero if the forward used batch statistics, zero if it used the running ones.
+// Backward of BatchNorm (over each graph's n_x live rows) + ReLU: dY (B,N,H) from dOut; per-graph
+// partial sums dgamma_p, dbeta_p, dbias_p (B,H).  Y holds the CENTRED pre-activation the forward
+// left there.  mode (device): non-zero if the forward used batch statistics, zero if it used the
+// running ones.
 int launch_bn_relu_bwd(const float *dOut, const float *Y, const float *bias, const float *out,
                        const float *gamma, const float *mean, const float *invstd,
                        const int32_t *n_x, int B, int N, int H, const int32_t *mode, float *dY,
@@ -119,17 +112,12 @@ struct ColsumGroup {
   }
 };
 int launch_colsum_group(const ColsumGroup &g, hipStream_t s);
-int launch_pool_fwd(const float *Hm, const int32_t *n_x, const int32_t *R, int B, int N, int H,
-                    float *gvec, hipStream_t s);
 int launch_pool_bwd(const float *dgvec, const int32_t *n_x, const int32_t *R, int B, int N, int H,
                     float *dH, hipStream_t s);
-int launch_reparam_fwd(const float *mu, const float *lvraw, const float *eps, int B, int Z, float *z,
-                       hipStream_t s);
 // dmu, dlvraw from dz and the KL term (coefficient c_kl / B per graph)
 int launch_reparam_bwd(const float *dz, const float *mu, const float *lvraw, const float *eps, int B,
                        int Z, float c_kl, const float *d_up, float *dmu, float *dlvraw,
                        hipStream_t s);
-int launch_relu_mask(float *dX, const float *act, int64_t n, hipStream_t s);
 int launch_prob(const float *vec, const float *node, int B, int N, float *P, hipStream_t s);
 int launch_loss_fwd(const float *vec, const float *node, const float *adj, const float *mu,
                     const float *lvraw, const int64_t *perm, const int32_t *R, int B, int N, int Z,
