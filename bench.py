@@ -26,7 +26,8 @@ The default matching path is "stream": the reference's algorithm with the (R,R,R
 similarity tensor materialised in HBM and streamed once per MPM iteration; that is the
 kernel the HBM roofline figure refers to.  The S-free fused path gives identical bits and is
 timed as well (reported under "fused").  Steps run as the trainer runs them: matching on a
-second stream beside backward + Adam, assignment + losses on a third, two steps in flight
+second stream beside backward + Adam, assignment + losses on a third (S-free matching: the whole
+matching half as one chain rotating over three streams), up to four steps in flight
 (GVAE_BENCH_PIPELINE=0: one step at a time); the timed region ends with a device-wide
 synchronisation, so every stream's work of the K steps is inside it.
 """

@@ -138,8 +138,8 @@ def _slot_attr(name):
 
 class StepEngine:
     """Runs forward / backward / optimiser of one GraphVAE step for batches of up to any
-    size; scratch is grown on demand and reused.  A caller that keeps two steps in flight
-    (the matching half of one step beside the model half of the next) alternates between two
+    size; scratch is grown on demand and reused.  A caller that keeps several steps in flight
+    (the matching half of one step beside the model half of the next ones) rotates over as many
     slots with `use_slot`; `perm`, `iters_done`, `out4` and the workspace are those of the
     current slot.  The similarity-tensor buffer is shared: matchings run one after the other."""
 

@@ -281,12 +281,14 @@ class TrainStep:
         once), hence both halves only need the decoder's logits; they are joined before the
         step returns.  Results are bit-identical to the sequential order.
         `pipeline` (needs overlap_matching): the step returns WITHOUT that join, so the matching
-        half of step N also runs beside the model half, backward and Adam of step N+1 (three
-        workspaces in rotation: `slots`, or the environment's GVAE_PIPELINE_SLOTS; a workspace is reused only
-        after its matching has finished.  With two, the forward of step N+2 waits for the
-        assignment of step N, and the chain model half -> matching -> assignment of one step,
-        0.45 ms of dependent work plus three cross-stream waits at 256 graphs of 32 nodes on the
-        S-free path, bounds two steps: 0.30 ms per step against 0.25 ms with three).
+        half of step N also runs beside the model half, backward and Adam of the following steps
+        (four workspaces in rotation: `slots`, or the environment's GVAE_PIPELINE_SLOTS; a workspace
+        is reused only after its matching has finished.  With the S-free matching the chain MPM ->
+        assignment -> losses of a step is latency-bound and outlives two further steps, so the
+        chains of consecutive steps rotate over three streams; with fewer workspaces than chains
+        in flight plus one, the forward of a step waits for the assignment of an earlier one:
+        0.30 ms per step with two workspaces against 0.25 with three at 256 graphs of 32 nodes
+        before the rotation, 0.23 ms with four and the rotation).
         The returned loss tensor, `model.last_permutations()` and `loss_sum` are then valid on
         the current stream only after `wait()`; parameters, gradients and optimiser state never
         depend on the matching and are always in stream order.
