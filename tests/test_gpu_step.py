@@ -484,7 +484,8 @@ def test_model_half_resident_kernel_equals_generic_kernel(N, train):
     of at most 128 nodes, hidden width 128) and a generic one that stages them through global
     memory; the first reads weight rows as 16-byte vectors, so a parameter buffer that starts
     4 bytes off that alignment takes the generic one.  Same activations, logits and BatchNorm
-    statistics from both, to fp32 rounding of differently ordered sums."""
+    statistics from both: the encoder of either runs in fp64 (matrix cores in one, plain fma chains
+    in the other), so the fp32 tensors they leave agree to a few units in the last place."""
     from graphvae.data import synthetic_batch
     from graphvae.models import GraphVAE
     B = 7
@@ -509,9 +510,7 @@ def test_model_half_resident_kernel_equals_generic_kernel(N, train):
     for k in got[0]:
         a, b = got[0][k], got[1][k]
         scale = max(b.abs().max().item(), 1e-6)
-        # (BatchNorm divides by a per-graph standard deviation: rounding differences of its input
-        # come out amplified, 5e-6 of the scale of H2 on these batches)
-        assert (a - b).abs().max().item() <= 2e-5 * scale, (k, (a - b).abs().max().item(), scale)
+        assert (a - b).abs().max().item() <= 2e-6 * scale, (k, (a - b).abs().max().item(), scale)
 
 
 @pytest.mark.gpu
