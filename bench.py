@@ -408,7 +408,10 @@ def main():
                                f"batch {main_leg['per_gpu_batch']} per GPU, deg features, hid 128, z 64, "
                                f"MPM iters<={args.mpm_iters} early_stop={early_stop}",
                    "matching": args.matching, "global_batch": main_leg["per_gpu_batch"] * world,
-                   "parallelism": f"dp{world}"},
+                   "parallelism": f"dp{world}",
+                   # the reference's precision everywhere at the boundary; inside, the encoder
+                   # forward (GCN layers, BatchNorm, pooling) is evaluated in fp64
+                   "precision": "fp32 tensors and matching; encoder forward in fp64"},
     }
     if roof is not None:
         line["roofline"] = roof
