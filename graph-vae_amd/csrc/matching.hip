@@ -491,13 +491,19 @@ __device__ __forceinline__ float norm_finish(float acc, const float *tail, int n
 // streaming phase of each link (measured: worth it below about a thousand items; every item
 // costs a ticket, a 4 KiB X load and an arrival, each a memory round trip).  The result nb satisfies
 // nb == ceil(R / ceil(R / nb)), so a consumer recovers the block width from nb alone.
-__host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low, int cap_kb) {
+__host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive, int low, int cap_kb,
+                                                       int t_cap) {
   const long long slab = 4LL * R * R * RS;
   const long long cap = (long long)cap_kb << 10;
   long long t = (slab + cap - 1) / cap;
   t = t < 1 ? 1 : t;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R * t;
   if (in_flight < low) t *= (low + in_flight - 1) / in_flight;
+  // the row maxima of a block (R rows of the block's width) must fit the LDS set aside for
+  // them: t_cap floats (the launch guarantees R * ceil(R / 8) <= t_cap for its largest graph)
+  const int aw_max = t_cap / R;
+  const int t_min = (R + aw_max - 1) / aw_max;
+  t = t < t_min ? t_min : t;
   int nb = t > MPM_MAX_COL_BLOCKS ? MPM_MAX_COL_BLOCKS : (int)t;
   nb = nb > R ? R : nb;
   for (;;) {
@@ -515,16 +521,16 @@ __host__ __device__ __forceinline__ int mpm_col_blocks(int R, int RS, int alive,
 //          the whole device) weigh more than the loss of parallelism, so items are made
 //          larger, up to about 512 KiB, as long as `high` items stay in flight.
 __host__ __device__ __forceinline__ int mpm_item_shape(int R, int RS, int alive, int low, int high,
-                                                       int cap_kb) {
+                                                       int cap_kb, int t_cap) {
   const long long slab = 4LL * R * R * RS;
   const long long in_flight = (long long)(alive < 1 ? 1 : alive) * R;
   int code = 0;
   // (items of up to 128 KiB are short enough that half as many in flight keep the device busy)
   for (int rpi = 8, c = 11; rpi >= 2; rpi >>= 1, --c)
-    if (!code && slab * rpi <= (512LL << 10) && rpi <= R &&
+    if (!code && slab * rpi <= (512LL << 10) && rpi <= R && R * R <= t_cap &&
         in_flight / rpi >= (slab * rpi <= (128LL << 10) ? high / 2 : high))
       code = c;
-  return code ? code : mpm_col_blocks(R, RS, alive, low, cap_kb);
+  return code ? code : mpm_col_blocks(R, RS, alive, low, cap_kb, t_cap);
 }
 __host__ __device__ __forceinline__ int mpm_shape_blocks(int code) { return code <= 8 ? code : 1; }
 __host__ __device__ __forceinline__ int mpm_shape_rows(int code) { return code <= 8 ? 1 : 2 << (code - 9); }
@@ -549,6 +555,11 @@ struct MpmQueue {
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
   int item_cap_kb;            // a row's slab above this many KiB is cut into column blocks
+  // LDS of a work-group after the control words: X of the item's graph (R padded rows), then
+  // t_cap floats for the row maxima of the item's column block (R x block width; a row is cut
+  // into at least as many blocks as that takes) and for the pieces in which the last arriver of
+  // an iteration folds the norm, then, x_floats + t_cap floats in, the diagonal factors
+  int t_cap, x_floats;
   // Hand-off of the latency-bound tail (gvae_match_stream only; handoff == nullptr: never).  Once
   // the slabs of all graphs still iterating add up to less than handoff_kb KiB, one pass over
   // them takes the device less time than the chain of dependent steps of one iteration (ticket,
@@ -573,6 +584,75 @@ __host__ __device__ __forceinline__ int mpm_slab_kb(int R, int RS) {
   return (int)(((long long)R * R * R * RS * 4 + 1023) >> 10);
 }
 
+// The last arriver of a graph's iteration: nrm = ||X_new||_2 in canonical order, X = X_new / nrm
+// written through to memory, and the largest |X - X_prev| of each wavefront in red[wave]
+// (infinity where a difference is NaN).  X_new was stored write-through by other work-groups
+// and is read past the vector cache.  The norm's chains run over X_new in LDS: a graph whose
+// X_new exceeds the t_cap floats at T passes through in pieces (a multiple of 8 elements each:
+// the 8 lane accumulators just continue) and takes the values from memory once more for the
+// division.  Not inlined: its registers are not the streaming loop's.  red[16] carries the norm.
+__device__ __noinline__ void mpm_renormalise(const float *Xn, float *Xg, int ldx, const float *Xs,
+                                             float *T, int t_cap, int R, int RS, float *red) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int R2 = R * R, n8 = R2 & ~7;
+  const bool whole = R2 <= t_cap;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < R2; c0 += t_cap) {
+    const int len = min(t_cap, R2 - c0);
+    if (c0) __syncthreads();                 // the previous piece has been consumed
+    // (four loads in flight per lane: each is a round trip to L2)
+    for (int e0 = tid; e0 < len; e0 += 4 * nt) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = __hip_atomic_load(&Xn[c0 + min(e0 + u * nt, len - 1)], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * nt < len) T[e0 + u * nt] = v[u];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      if (tid < 8) acc = norm_chain(T, min(n8 - c0, len) & ~7, tid, acc);
+      if (c0 + len == R2) {
+        const float nrm = norm_finish(acc, T + (n8 - c0), R2 - n8);
+        if (tid == 0) red[16] = nrm;
+      }
+    }
+  }
+  __syncthreads();
+  const float nrm = red[16];
+  float dmax = 0.f;
+  bool isnan_any = false;
+  auto renormalise = [&](int e, float xn) {
+    const float v = xn / nrm;
+    const int r = e / R, c = e - r * R;
+    const float d = fabsf(v - Xs[r * RS + c]);
+    isnan_any |= (d != d);
+    dmax = fmaxf(dmax, d);
+    // write-through: the next iteration's consumers run on other compute units
+    __hip_atomic_store(&Xg[(int64_t)r * ldx + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (whole) {
+    for (int e = tid; e < R2; e += nt) renormalise(e, T[e]);
+  } else {
+    for (int e0 = tid; e0 < R2; e0 += 4 * nt) {
+      float xn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        xn[u] = __hip_atomic_load(&Xn[min(e0 + u * nt, R2 - 1)], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * nt < R2) renormalise(e0 + u * nt, xn[u]);
+    }
+  }
+  if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
+  dmax = wave_max(dmax);
+  if ((tid & 63) == 0) red[tid >> 6] = dmax;
+  __syncthreads();
+}
+
 __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAVES))) void mpm_stream_kernel(const float *__restrict__ S, const int64_t *__restrict__ S_off,
                                   const int32_t *__restrict__ Rarr, int r_max,
                                   float *__restrict__ X, int ldx, int64_t strideX,
@@ -584,7 +664,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
   // 16-byte alignment that the 128-bit LDS reads of X need (misaligned ones are replayed).
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   float *red = lds_all;                                  // [16]
-  float &s_nrm = lds_all[16];
   int *ctl = reinterpret_cast<int *>(lds_all + 17);
   int &s_item = ctl[0], &s_R = ctl[1], &s_last = ctl[2], &s_cont = ctl[3], &s_base = ctl[4],
       &s_nb = ctl[5], &s_done = ctl[6], &s_alive = ctl[7], &s_alive_kb = ctl[8];
@@ -655,8 +734,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       const int Aw_full = (R + n_blk - 1) / n_blk;
       const int a0 = q_blk * Aw_full, Aw = min(Aw_full, R - a0);
       float *Xs = lds;            // R rows of RS floats (padding repeats the last element)
-      float *T = lds + R * RS;    // R*R
-      float *nsrow = T + R2;      // rows_here * R
+      float *T = lds + R * RS;    // R * Aw (the last arriver: pieces of up to t_cap floats)
+      float *nsrow = lds + q.x_floats + q.t_cap;   // rows_here * R
       float *Xg = X + g * strideX;
       float *Xn = Xnew + g * strideXnew;
       // X was written by another work-group of this launch (write-through stores, drained
@@ -722,41 +801,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       if (s_last) {
         // ---- last arriver: normalise the graph
         // (the other producers' rows: write-through stores, read past the vector cache)
-        for (int e0 = tid; e0 < R2; e0 += 4 * nt) {
-          float v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            v[u] = __hip_atomic_load(&Xn[min(e0 + u * nt, R2 - 1)], __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (e0 + u * nt < R2) T[e0 + u * nt] = v[u];
-        }
-        __syncthreads();
-        const int n8 = R2 & ~7;
-        if (tid < 64) {
-          float acc = 0.f;
-          if (tid < 8) acc = norm_chain(T, n8, tid, acc);
-          const float nrm = norm_finish(acc, T + n8, R2 - n8);
-          if (tid == 0) s_nrm = nrm;
-        }
-        __syncthreads();
-        const float nrm = s_nrm;
-        float dmax = 0.f;
-        bool isnan_any = false;
-        for (int e = tid; e < R2; e += nt) {
-          const float v = T[e] / nrm;
-          const int r = e / R, c = e - r * R;
-          const float d = fabsf(v - Xs[r * RS + c]);
-          isnan_any |= (d != d);
-          dmax = fmaxf(dmax, d);
-          // write-through: the next iteration's consumers run on other compute units
-          __hip_atomic_store(&Xg[(int64_t)r * ldx + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (isnan_any) dmax = INFINITY;  // a NaN difference never satisfies `< tol`
-        dmax = wave_max(dmax);
-        if ((tid & 63) == 0) red[tid >> 6] = dmax;
-        __syncthreads();
+        mpm_renormalise(Xn, Xg, ldx, Xs, T, q.t_cap, R, RS, red);
         if (tid == 0) {
           float d = red[0];
           for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
@@ -785,7 +830,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
             __hip_atomic_fetch_add(Q_ALIVE_KB(q), -mpm_slab_kb(R, RS), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
           if (cont) {
-            const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high, q.item_cap_kb);
+            const int shape_next = mpm_item_shape(R, RS, s_alive, q.low, q.high, q.item_cap_kb, q.t_cap);
             s_nb = shape_next;
             s_base = __hip_atomic_fetch_add(Q_TAIL(q), mpm_shape_items(R, shape_next),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -848,7 +893,7 @@ __global__ __launch_bounds__(1024) void mpm_queue_init_kernel(MpmQueue q,
     if (R > r_max) *Q_ERROR(q) = 3;        // larger than the launch was sized for: not run, reported
     if (R <= 0 || R > r_max) { shape = 0; return 0; }
     if (first_stop && ((first_stop[g] & 1) != 0 || iters_done[g] >= iters)) { shape = 0; return 0; }
-    shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high, q.item_cap_kb);
+    shape = mpm_item_shape(R, s_row_stride(R, layout), n_graphs, q.low, q.high, q.item_cap_kb, q.t_cap);
     return mpm_shape_items(R, shape);
   };
   __shared__ int s_kb;
@@ -2153,9 +2198,26 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
                GVAE_ELIMIT, "mpm_stream: too many graphs (n_graphs=%d, r_max=%d)", n_graphs, r_max);
   GVAE_REQUIRE(s_layout == GVAE_S_DENSE || s_layout == GVAE_S_PADDED, GVAE_EINVAL,
                "mpm_stream: unknown S layout %d", s_layout);
-  // X (padded rows) | T | the diagonal factors of an item's rows (up to 8 rows of small graphs)
-  const size_t lds = sizeof(float) * (kCtlFloats + (size_t)r_max * ((r_max + 3) & ~3) +
-                                      (size_t)r_max * r_max + (size_t)(r_max > 256 ? r_max : 256));
+  // control words | X (padded rows) | T: row maxima of an item's column block, pieces of X_new for
+  // the norm | the diagonal factors of an item's rows (up to 8 rows of small graphs)
+  const size_t x_floats = (size_t)r_max * ((r_max + 3) & ~3);
+  const size_t ns_floats = (size_t)(r_max > 256 ? r_max : 256);
+  // Two work-groups per compute unit need 79 KiB or less each.  Where T for whole rows
+  // (r_max^2 floats) does not leave that, T gets what is left of the 79 KiB and the rows of the
+  // large graphs are cut into as many column blocks as it takes (99 nodes: 3, 120 nodes: 3).
+  // From 121 nodes on, where X alone takes most of the 79 KiB, one work-group per unit with T
+  // for whole rows: uniform batches measured 6.69 against 6.58 TB/s at 126 nodes and 0.888
+  // against 0.877 of the HBM peak at 128 that way, although a ragged batch with one 126-node
+  // graph would stream at 5.1 instead of 4.7 TB/s with T bounded.
+  constexpr size_t kHalfCuLds = 79 * 1024;
+  size_t t_cap = (size_t)r_max * r_max;
+  const size_t fixed = sizeof(float) * (kCtlFloats + x_floats + ns_floats);
+  if (fixed + sizeof(float) * t_cap > kHalfCuLds && fixed < kHalfCuLds && r_max <= 120) {
+    const size_t room = ((kHalfCuLds - fixed) / sizeof(float)) & ~(size_t)7;
+    if (room >= (size_t)r_max * ceil_div(r_max, MPM_MAX_COL_BLOCKS)) t_cap = room;
+  }
+  t_cap = (t_cap + 7) & ~(size_t)7;
+  const size_t lds = fixed + sizeof(float) * t_cap;
   GVAE_REQUIRE(lds <= kMaxDynLds, GVAE_ELIMIT, "mpm_stream: r_max=%d needs %zu bytes of LDS", r_max,
                lds);
   if (n_graphs == 0) return GVAE_OK;
@@ -2187,13 +2249,17 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   GVAE_REQUIRE(reinterpret_cast<char *>(q.slots) == reinterpret_cast<char *>(q.words) + 512 &&
                    hipMemsetAsync(q.words, 0, 512 + 8 * (size_t)n_items, s) == hipSuccess,
                GVAE_ELAUNCH, "mpm_stream: memset failed");
-  // Work-group size.  256 threads (several work-groups per CU, whose per-item phases overlap)
-  // stream faster than 1024 at every size whose rows are not a multiple of 128 bytes -- steady
-  // state, TB/s at 256 / 1024 threads: 48 nodes 6.09 / 4.64, 52: 5.61 / 4.44, 57: 5.32 / 4.53,
-  // 70: 5.52 / 5.11, 82: 5.59 / 4.95, 96: 6.93 / 6.82 -- and on ragged batches; 1024 wins at
-  // exactly 64 nodes (6.97 against 6.69) and is the only shape that keeps a CU busy once the
-  // LDS of an item (X and the row maxima of the largest graph) leaves room for one work-group.
-  int nt = (r_max == 64 || 2 * (lds + 1024) > 160 * 1024) ? 1024 : 256;
+  // Work-group size.  What counts is how many wavefronts a compute unit holds beside the one
+  // that is between two items (ticket, X reload, arrival: nothing of its own overlaps these):
+  // 256 threads while three or four work-groups fit, 512 threads in two work-groups beyond that,
+  // 1024 in one only where X alone leaves no room for a second.  Steady state, TB/s at 256 / 1024
+  // threads: 48 nodes 6.09 / 4.64, 52: 5.61 / 4.44, 57: 5.32 / 4.53, 70: 5.52 / 5.11; 1024 wins
+  // at exactly 64 nodes (6.97 against 6.69).  At 256 / 512 threads: 76 nodes 5.59 / 6.06, 82:
+  // 5.26 / 5.39, 88: 5.63 / 5.87, 98: 4.58 / 5.35, and ragged batches of 64 graphs whose largest
+  // has 84 ... 91 nodes 4.05-4.43 / 4.61-5.20 (70 nodes: 5.14 / 4.96, 75: the same).  With T
+  // bounded, 512 / 1024 threads: 99 nodes 4.72 / 4.51, 104: 5.73 / 5.23, 112: 6.11 / 5.73, 120:
+  // 6.00 / 5.45, ragged batches with one graph of 99 ... 111 nodes 4.73-5.22 / 4.09-4.57.
+  const int nt = (r_max == 64 || 2 * (lds + 1024) > 160 * 1024) ? 1024 : (r_max >= 76 ? 512 : 256);
   // Items in flight below which rows are cut finer, and the size above which a row's slab is cut
   // in any case: with 256-thread work-groups an item of a large graph would otherwise run for
   // 100-270 us (a work-group streams 5-20 GB/s) and a round of a small batch ends on a few such
@@ -2201,11 +2267,14 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
   // (1024, 256, 2048) 3.29, (256, 1024, 2048) 3.02, (256, 1024, 1024) 2.89, (256, 1024, 512)
   // 2.67, (256, 1024, 256) 2.66, (256, 1024, 128) 2.84.  With 1024-thread work-groups only 256
   // are resident, and cutting finer than there are work-groups to take the pieces only adds
-  // rounds of items.  Rows are grouped (high) while many small slabs are in flight: 16-node
+  // rounds of items (512 threads, 512 resident: 1024 KiB and 512 items measured the same as
+  // 512 KiB and 1024).  Rows are grouped (high) while many small slabs are in flight: 16-node
   // graphs 3.0 -> 1.5 ms per 1024, 24-node 3.1 -> 2.4 ms per 512.
-  q.low = nt == 1024 ? 256 : 1024;
+  q.low = nt == 1024 ? 256 : (nt == 512 ? 512 : 1024);
   q.high = 4096;
-  q.item_cap_kb = nt == 1024 ? 2048 : 512;
+  q.item_cap_kb = nt == 1024 ? 2048 : (nt == 512 ? 1024 : 512);
+  q.t_cap = (int)t_cap;
+  q.x_floats = (int)x_floats;
   // measured on launches whose LDS leaves one work-group per CU (128-node graphs; ragged batches
   // up to 126): 0.877 against 0.89 of HBM peak, no change on the ragged batch -- off
   q.two_buffers = 0;
@@ -2216,13 +2285,13 @@ static int mpm_stream_launch(const float *d_S, const int64_t *d_S_off, int s_lay
     GVAE_REQUIRE(e == hipSuccess, GVAE_ELAUNCH, "mpm_stream: cannot reserve %zu bytes of LDS: %s",
                  lds, hipGetErrorString(e));
   }
-  // at least as many work-groups as can be resident (256 CUs x <= 8); surplus ones start when
-  // others leave, which only happens once every graph is finished, and then leave at once
+  // at least as many work-groups as can be resident (256 CUs x 4, 2 or 1); surplus ones start
+  // when others leave, which only happens once every graph is finished, and then leave at once.
   // 256-thread launches: four work-groups per CU instead of the five that fit.  The fifth adds
   // nothing to the streaming rate (measured), and the quarter of the register file it would
   // take is what lets kernels of other streams (the backward's GEMMs, 128 registers) run beside
   // this persistent kernel instead of queueing until it ends.
-  int max_blocks = nt == 256 ? 1024 : 2048 * 256 / nt;
+  const int max_blocks = nt == 256 ? 1024 : 512;
   const int blocks = n_items < max_blocks ? (int)n_items : max_blocks;
   hipLaunchKernelGGL(mpm_queue_init_kernel, dim3(1), dim3(1024), 0, s, q, d_R, n_graphs, r_max,
                      s_layout, d_iters_done, first_stop, iters);

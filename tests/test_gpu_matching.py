@@ -190,11 +190,17 @@ def test_fused_supports_every_size_up_to_128(hip):
 
 @pytest.mark.parametrize("sizes,N,cfg", [((116, 120, 126, 127, 128), 128, (6, 1e-4, True)),
                                          ((89, 96, 97, 113, 128, 7, 30, 64), 128, (5, 1e-4, False)),
-                                         ((126,) + (31, 12, 44, 57, 2, 23, 38, 19, 70), 126, (50, 1e-4, True))])
+                                         ((126,) + (31, 12, 44, 57, 2, 23, 38, 19, 70), 126, (50, 1e-4, True)),
+                                         ((120, 113, 99, 77, 64, 30, 8, 1), 120, (6, 1e-4, True)),
+                                         ((104, 103, 50, 3), 104, (5, 1e-4, False)),
+                                         ((91, 84, 76, 45, 13), 91, (7, 1e-4, True))])
 def test_sfree_mpm_above_115_nodes(hip, sizes, N, cfg):
     """Launches whose largest graph has 89..128 nodes (the row maxima take X's place in LDS), with
     smaller graphs beside it: stream == fused == oracle, bit for bit, and the same permutations.
-    The last case is one 126-node graph in an ENZYMES-shaped batch with the reference's defaults."""
+    The third case is one 126-node graph in an ENZYMES-shaped batch with the reference's defaults.
+    The streamed launch of the last three runs 512-thread work-groups; at 99..120 nodes the row
+    maxima in LDS are bounded to a column block and the norm of a large graph is folded in two or
+    three pieces."""
     rng = np.random.default_rng(sum(sizes))
     As, Ps = [], []
     for R in sizes:
