@@ -264,6 +264,9 @@ __device__ __forceinline__ float group_max_ct(float m) {
   if constexpr (LPR_LOG2 >= 2) m = dpp_max_xor2(m);
   if constexpr (LPR_LOG2 >= 3) m = dpp_max_half_mirror(m);
   if constexpr (LPR_LOG2 >= 4) m = dpp_max_mirror(m);
+  // 32 lanes: the other row of 16 through the LDS crossbar (swap with lane ^ 16)
+  if constexpr (LPR_LOG2 >= 5)
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));
   return m;
 }
 
@@ -377,6 +380,11 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
   // 5.41 / 6.19, 57: 5.20 / 5.90, 60: 5.56 / 6.25, 70: 5.39 / 5.97, 75: 5.25 / 5.43; from 21
   // vectors on (82 nodes: 5.25 / 4.56) the idle lanes of the second pass cost more.
   if (V == 4 && wide && (cols & 7) != 0 && cols > 8 && cols <= 19) lpr_log2 = 4;
+  // The same from 20 vectors on with 32 lanes per row (two whole rows per instruction), TB/s with
+  // 8 lanes x 3 or 4 passes / 32 lanes: 78 nodes 6.15 / 6.31, 82: 5.41 / 6.05, 91: 5.66 / 6.36,
+  // 99: 5.42 / 6.44, 104: 5.74 / 6.49, 118: 5.82 / 6.40; below that the idle lanes weigh more
+  // (16 lanes x 2 passes / 32 lanes: 66 nodes 5.56 / 5.19, 70: 5.96 / 5.74, 75: 5.39 / 5.13).
+  if (V == 4 && wide && (cols & 7) != 0 && cols >= 20 && cols <= 32) lpr_log2 = 5;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
   constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
   if constexpr (V == 4) {
@@ -393,6 +401,7 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
       case 4 * 8 + 1: return mpm_iter_body_v4<4, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
       case 4 * 8 + 2: return mpm_iter_body_v4<4, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
       case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 5 * 8 + 1: return mpm_iter_body_v4<5, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
       default: break;
     }
   }
@@ -551,7 +560,7 @@ struct MpmQueue {
   int32_t *arrive;            // [n_graphs]
   unsigned cap;
   int two_buffers;            // one work-group per compute unit: two steps of loads in flight
-  int wide_rows;              // 16 lanes per row for rows that are not a multiple of 128 bytes
+  int wide_rows;              // 16 or 32 lanes per row for rows that are not a multiple of 128 bytes
   int low;                    // items in flight below which rows are cut into more column blocks
   int high;                   // items in flight that must remain when rows are grouped
   int item_cap_kb;            // a row's slab above this many KiB is cut into column blocks

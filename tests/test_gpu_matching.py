@@ -407,11 +407,11 @@ def test_argument_errors(hip):
         hip.lsap(A, R, 200)
 
 
-@pytest.mark.parametrize("R", [1, 44, 70, 100, 131, 140])
+@pytest.mark.parametrize("R", [1, 44, 70, 78, 87, 100, 131, 140])
 def test_stream_row_shapes_vs_oracle(hip, R):
-    """One case per row shape of the streaming loop (lanes per row x passes: 44 -> 8x2, 70 -> 8x3,
-    100 -> 8x4, 131 and 140 -> 16x3; 1 is the degenerate single row): three iterations of the
-    streamed MPM on the materialised tensor equal the S-free oracle bit for bit."""
+    """One case per row shape of the streaming loop (lanes per row x passes: 44 -> 16x1, 70 -> 16x2,
+    78, 87 and 100 -> 32x1, 131 and 140 -> 16x3; 1 is the degenerate single row): three iterations
+    of the streamed MPM on the materialised tensor equal the S-free oracle bit for bit."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(1000 + R)
     up = np.triu((rng.random((R, R)) < 0.4).astype(np.float32), 1)
