@@ -160,6 +160,31 @@ __device__ __forceinline__ void vec_to_arr(const typename VecT<V>::type &v, floa
 #ifndef GVAE_STREAM_NT
 #define GVAE_STREAM_NT 1
 #endif
+// A pointer argument of a function that is not inlined is a generic one (flat instructions,
+// which wait on the LDS counter as well); these say that it points to device memory.
+#define GVAE_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GVAE_GLOBAL T *as_global(T *p) {
+  return (GVAE_GLOBAL T *)(uintptr_t)p;
+}
+// Its arguments also arrive in vector registers, as if they differed between lanes: these say that
+// a value is the same in every lane (scalar registers, scalar address arithmetic, uniform loops).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ GVAE_GLOBAL T *uniform_global(T *p) {
+  const uintptr_t a = (uintptr_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (GVAE_GLOBAL T *)(((uintptr_t)hi << 32) | lo);
+}
+__device__ __forceinline__ f32x4_t stream_load4(const GVAE_GLOBAL float *p) {
+#if GVAE_STREAM_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const GVAE_GLOBAL f32x4_t *>(p));
+#else
+  return *reinterpret_cast<const GVAE_GLOBAL f32x4_t *>(p);
+#endif
+}
+
 template <int V>
 __device__ __forceinline__ typename VecT<V>::type stream_load(const float *p) {
   using vec_t = typename VecT<V>::type;
@@ -283,7 +308,7 @@ struct RowStep {
 
 template <int LPR_LOG2, int PASSES, int RB>
 __device__ __forceinline__ void row_step_issue(RowStep<LPR_LOG2, PASSES, RB> &st,
-                                               const float *__restrict__ slab, int R, int RS, int a0,
+                                               const GVAE_GLOBAL float *__restrict__ slab, int R, int RS, int a0,
                                                int Aw, float inv_aw, int NR, int first_row, int rpp,
                                                const int (&coff)[PASSES]) {
 #pragma unroll
@@ -291,11 +316,11 @@ __device__ __forceinline__ void row_step_issue(RowStep<LPR_LOG2, PASSES, RB> &st
     const int r = min(first_row + rb * rpp, NR - 1);
     const int j = (int)(((float)r + 0.5f) * inv_aw);
     const int al = r - __mul24(j, Aw);
-    const float *src = slab + (unsigned)__mul24(__mul24(j, R) + a0 + al, RS);
+    const GVAE_GLOBAL float *src = slab + (unsigned)__mul24(__mul24(j, R) + a0 + al, RS);
     st.jX[rb] = __mul24(j, RS);
     st.rw[rb] = r;
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) st.sv[rb][p] = stream_load<4>(src + coff[p]);
+    for (int p = 0; p < PASSES; ++p) st.sv[rb][p] = stream_load4(src + coff[p]);
   }
 }
 
@@ -321,8 +346,8 @@ __device__ __forceinline__ void row_step_reduce(const RowStep<LPR_LOG2, PASSES, 
 }
 
 template <int LPR_LOG2, int PASSES, int RB, bool TWO = false>
-__device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab, int R, int RS,
-                                                 int a0, int Aw, const float *Xs, float *T) {
+__device__ __forceinline__ void mpm_iter_rows_v4(const GVAE_GLOBAL float *__restrict__ slab, int R,
+                                                 int RS, int a0, int Aw, const float *Xs, float *T) {
   constexpr int LPR = 1 << LPR_LOG2;
   int tid = threadIdx.x;
   // opaque to the optimiser: what derives from the lane number is computed here, per call,
@@ -362,6 +387,65 @@ __device__ __forceinline__ void mpm_iter_body_v4(const float *__restrict__ slab,
   }
 }
 
+// The shapes as functions of their own: each gets registers of its own, whatever else the kernel
+// around it holds.  X and T are offsets into the work-group's dynamic LDS.
+template <int LPR_LOG2, int PASSES, int RB, bool TWO = false>
+__device__ __noinline__ void mpm_iter_body_v4(const float *__restrict__ slab_, int R, int RS,
+                                              int a0, int Aw, int xs_off, int t_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  R = uniform(R), RS = uniform(RS), a0 = uniform(a0), Aw = uniform(Aw);
+  mpm_iter_rows_v4<LPR_LOG2, PASSES, RB, TWO>(uniform_global(slab_), R, RS, a0, Aw,
+                                              lds_all + uniform(xs_off), lds_all + uniform(t_off));
+}
+
+// Rows of `cols` 16-byte vectors, k = 64 / cols whole consecutive rows per load instruction of a
+// wavefront (lane l: row l / cols of the k, vector l % cols): one contiguous run of memory per
+// instruction and at most cols - 1 idle lanes, for row lengths that no power-of-two group of
+// lanes fits.  The lanes of a row fold their maxima into T[row] with LDS atomics (fp32 max is
+// exact, so the order does not matter).
+// Not inlined: its registers are not the other shapes'.  X and T are passed as offsets into the
+// work-group's dynamic LDS (a pointer argument would be a generic one: flat instead of LDS
+// instructions).
+template <int RB>
+__device__ __noinline__ void mpm_iter_body_flat(const float *__restrict__ slab, int R, int RS,
+                                                int a0, int Aw, int xs_off, int t_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  R = uniform(R), RS = uniform(RS), a0 = uniform(a0), Aw = uniform(Aw);
+  const float *Xs = lds_all + uniform(xs_off);
+  float *T = lds_all + uniform(t_off);
+  const GVAE_GLOBAL float *gslab = uniform_global(slab);
+  const int tid = threadIdx.x;
+  const int nw = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+  const int NR = R * Aw, cols = RS >> 2;
+  for (int e = tid; e < NR; e += blockDim.x) T[e] = -INFINITY;
+  __syncthreads();
+  const int k = 64 / cols;
+  const int rsub = (int)(((float)lane + 0.5f) * (1.0f / (float)cols));
+  const int cvec4 = (lane - rsub * cols) * 4;
+  const float inv_aw = 1.0f / (float)Aw;
+  if (rsub < k) {
+    for (int base = 0; base < NR; base += nw * k * RB) {
+      f32x4_t sv[RB];
+      int jX[RB], rw[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int r = min(base + (rb * nw + wave) * k + rsub, NR - 1);
+        const int j = (int)(((float)r + 0.5f) * inv_aw);
+        const int al = r - __mul24(j, Aw);
+        sv[rb] = stream_load4(gslab + (unsigned)(__mul24(__mul24(j, R) + a0 + al, RS) + cvec4));
+        jX[rb] = __mul24(j, RS) + cvec4;
+        rw[rb] = r;
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t *>(Xs + jX[rb]);
+        float m = fmaxf(fmaxf(sv[rb].x * x.x, sv[rb].y * x.y), fmaxf(sv[rb].z * x.z, sv[rb].w * x.w));
+        __hip_atomic_fetch_max(&T[rw[rb]], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+}
+
 // picks the lanes-per-row exponent and the pass count for rows of `cols` vectors of V floats:
 // 128-byte pieces per row per load instruction where the row is long enough, at most 4 passes
 template <int V, bool TWO = false>
@@ -387,21 +471,37 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
   if (V == 4 && wide && (cols & 7) != 0 && cols >= 20 && cols <= 32) lpr_log2 = 5;
   const int passes = (cols + (1 << lpr_log2) - 1) >> lpr_log2;
   constexpr int D = GVAE_STREAM_DEPTH;  // loads in flight per lane
+  if constexpr (V == 4 && !TWO) {
+    // rows of 9 or 10 vectors (33 ... 40 nodes), which leave 16 lanes per row nearly half idle:
+    // seven or six whole rows per instruction.  TB/s, 16 lanes per row / whole rows: 36 nodes
+    // 5.57 / 6.19, 40: 5.97 / 6.21; not where the gain in busy lanes is smaller than what the
+    // LDS atomics cost (24 nodes 4.99 / 5.17, 44: 6.10 / 6.19, 52: 6.18 / 5.85, 66: 5.56 / 5.42,
+    // 70: 5.96 / 5.77, 75: 5.37 / 5.51)
+    if (wide && (cols == 9 || cols == 10)) {
+      extern __shared__ __attribute__((aligned(16))) float lds_all[];
+      return mpm_iter_body_flat<D>(slab, R, RS, a0, Aw, (int)(Xs - lds_all), (int)(T - lds_all));
+    }
+  }
   if constexpr (V == 4) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int xs_off = (int)(Xs - lds_all), t_off = (int)(T - lds_all);
     // every shape up to 35 vectors per row (R <= 140, the LDS limit of the kernel)
     const int key = lpr_log2 * 8 + passes;
     switch (key) {
-      case 0 * 8 + 1: return mpm_iter_body_v4<0, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 1 * 8 + 1: return mpm_iter_body_v4<1, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 2 * 8 + 1: return mpm_iter_body_v4<2, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 1: return mpm_iter_body_v4<3, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 2: return mpm_iter_body_v4<3, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 4 * 8 + 1: return mpm_iter_body_v4<4, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 4 * 8 + 2: return mpm_iter_body_v4<4, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, Xs, T);
-      case 5 * 8 + 1: return mpm_iter_body_v4<5, 1, D, TWO>(slab, R, RS, a0, Aw, Xs, T);
+      case 0 * 8 + 1: return mpm_iter_rows_v4<0, 1, D, TWO>(as_global(slab), R, RS, a0, Aw, Xs, T);
+      case 1 * 8 + 1: return mpm_iter_rows_v4<1, 1, D, TWO>(as_global(slab), R, RS, a0, Aw, Xs, T);
+      case 2 * 8 + 1: return mpm_iter_rows_v4<2, 1, D, TWO>(as_global(slab), R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 1: return mpm_iter_rows_v4<3, 1, D, TWO>(as_global(slab), R, RS, a0, Aw, Xs, T);
+      // (inline: rows of up to 8 vectors, whose calls are short -- 16 ... 24 nodes measured 3-5 %
+      // slower as functions -- and 64-node rows, 0.856 against 0.889 of the HBM peak)
+      case 3 * 8 + 2:
+        return mpm_iter_rows_v4<3, 2, (D + 1) / 2, TWO>(as_global(slab), R, RS, a0, Aw, Xs, T);
+      case 3 * 8 + 3: return mpm_iter_body_v4<3, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
+      case 3 * 8 + 4: return mpm_iter_body_v4<3, 4, (D + 3) / 4, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
+      case 4 * 8 + 1: return mpm_iter_body_v4<4, 1, D, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
+      case 4 * 8 + 2: return mpm_iter_body_v4<4, 2, (D + 1) / 2, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
+      case 4 * 8 + 3: return mpm_iter_body_v4<4, 3, (D + 2) / 3, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
+      case 5 * 8 + 1: return mpm_iter_body_v4<5, 1, D, TWO>(slab, R, RS, a0, Aw, xs_off, t_off);
       default: break;
     }
   }
@@ -599,9 +699,18 @@ __host__ __device__ __forceinline__ int mpm_slab_kb(int R, int RS) {
 // and is read past the vector cache.  The norm's chains run over X_new in LDS: a graph whose
 // X_new exceeds the t_cap floats at T passes through in pieces (a multiple of 8 elements each:
 // the 8 lane accumulators just continue) and takes the values from memory once more for the
-// division.  Not inlined: its registers are not the streaming loop's.  red[16] carries the norm.
-__device__ __noinline__ void mpm_renormalise(const float *Xn, float *Xg, int ldx, const float *Xs,
-                                             float *T, int t_cap, int R, int RS, float *red) {
+// division.  Not inlined: its registers are not the streaming loop's.  X and T are offsets into
+// the work-group's dynamic LDS (pointer arguments would be generic ones: flat instead of LDS
+// instructions); red = its first floats, red[16] carries the norm.
+__device__ __noinline__ void mpm_renormalise(const float *Xn_, float *Xg_, int ldx, int xs_off,
+                                             int t_off, int t_cap, int R, int RS) {
+  const GVAE_GLOBAL float *Xn = uniform_global(Xn_);
+  GVAE_GLOBAL float *Xg = uniform_global(Xg_);
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  ldx = uniform(ldx), t_cap = uniform(t_cap), R = uniform(R), RS = uniform(RS);
+  float *red = lds_all;
+  const float *Xs = lds_all + uniform(xs_off);
+  float *T = lds_all + uniform(t_off);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int R2 = R * R, n8 = R2 & ~7;
   const bool whole = R2 <= t_cap;
@@ -810,7 +919,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(GVAE_STREAM_WAVES, GVAE_STREAM_WAV
       if (s_last) {
         // ---- last arriver: normalise the graph
         // (the other producers' rows: write-through stores, read past the vector cache)
-        mpm_renormalise(Xn, Xg, ldx, Xs, T, q.t_cap, R, RS, red);
+        mpm_renormalise(Xn, Xg, ldx, (int)(Xs - lds_all), (int)(T - lds_all), q.t_cap, R, RS);
         if (tid == 0) {
           float d = red[0];
           for (int w = 1; w < (nt >> 6); ++w) d = fmaxf(d, red[w]);
