@@ -45,6 +45,10 @@ for p in (str(ROOT), str(ROOT / "graph-vae_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# RCCL between processes needs dmabuf IPC handles on this driver (hipIpcGetMemHandle fails with the
+# legacy mode); set before anything initialises the GPU, inherited by the ranks this script starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -545,6 +545,8 @@ def _ddp_worker(rank: int, world: int, args) -> None:
     spawned = False
     if world > 1 and not dist.is_initialized():
         require_one_gpu_per_rank(world)
+        # (dmabuf IPC handles: the legacy mode fails in hipIpcGetMemHandle on this driver)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
