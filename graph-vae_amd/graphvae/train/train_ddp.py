@@ -545,8 +545,6 @@ def _ddp_worker(rank: int, world: int, args) -> None:
     spawned = False
     if world > 1 and not dist.is_initialized():
         require_one_gpu_per_rank(world)
-        # (dmabuf IPC handles: the legacy mode fails in hipIpcGetMemHandle on this driver)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
@@ -661,6 +659,9 @@ _DEFAULTS = dict(
 
 
 def train(cfg) -> None:
+    # RCCL between processes needs dmabuf IPC handles on this driver (hipIpcGetMemHandle fails in the
+    # legacy mode): set before anything initialises the GPU here, inherited by spawned workers
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if isinstance(cfg, dict):
         cfg = SimpleNamespace(**cfg.get("trainer", cfg))
     for k, v in _DEFAULTS.items():
