@@ -470,6 +470,47 @@ def test_dense_layout_wide_workgroups(hip):
     assert int(dp[0]) == done and np.array_equal(Xp[0, :49, :49].cpu().numpy(), Xo)
 
 
+@pytest.mark.parametrize("seed", [1, 8, 14, 18, 3])
+def test_enzymes_shaped_batches_stream_equals_sfree(hip, seed):
+    """ENZYMES-shaped batches of 64 graphs at the reference's defaults (50 iterations, tol 1e-4,
+    early stop) whose largest graph has 75 / 91 / 99 / 111 / 126 nodes -- one per launch shape of the
+    streaming kernel (256-thread work-groups; 512 threads; 512 threads with the row maxima bounded
+    to a column block and the norm folded in pieces, twice; 1024 threads): the streamed matching,
+    the streamed matching with the tail handed off and the S-free matching agree bit for bit in X
+    and in the iteration counts, and give the same permutations."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "graph-vae_amd"))
+    from graphvae.data import synthetic_batch
+    dev = torch.device("cuda:0")
+    N = 126
+    batch = synthetic_batch("enzymes", 64, N, "deg", seed=seed).to(dev)
+    Rh = list(batch.r_host)
+    assert max(Rh) == {1: 75, 8: 91, 14: 99, 18: 111, 3: 126}[seed]
+    A = batch.adj_dense.contiguous()
+    gen = torch.Generator().manual_seed(seed)
+    lg = torch.triu(torch.randn(64, N, N, generator=gen) * 0.3, 1)
+    P = torch.sigmoid(lg + lg.transpose(1, 2)).to(dev).contiguous()
+    R = batch.num_real_nodes
+    NS = hip.node_sim(A, P, R)
+    r_max = max(Rh)
+    S, S_off = hip.edge_sim(A, P, NS, R, Rh, hip.S_PADDED)
+    Xs = hip.x0_uniform(Rh, N, dev)
+    done_s = hip.mpm_stream(S, S_off, R, r_max, Xs, 50, 1e-4, True, layout=hip.S_PADDED)
+    Xf = hip.x0_uniform(Rh, N, dev)
+    done_f = hip.mpm_fused(A, P, NS, R, r_max, Xf, 50, 1e-4, True)
+    Xm = torch.zeros_like(Xs)
+    _S, _off, done_m = hip.match_stream(A, P, NS, R, Rh, Xm, 50, 1e-4, True)
+    assert torch.equal(done_s, done_f) and torch.equal(done_m, done_f)
+    assert int(done_f.min()) >= 1 and int(done_f.max()) <= 50
+    for g, r in enumerate(Rh):
+        assert torch.equal(Xs[g, :r, :r], Xf[g, :r, :r]), (g, r)
+        assert torch.equal(Xm[g, :r, :r], Xf[g, :r, :r]), (g, r)
+    perm_s, st_s = hip.lsap(Xs, R, r_max)
+    perm_f, st_f = hip.lsap(Xf, R, r_max)
+    assert torch.equal(perm_s, perm_f) and int(st_s.abs().sum()) == 0 and int(st_f.abs().sum()) == 0
+
+
 def test_match_stream_tail_handoff(hip):
     """gvae_match_stream hands the latency-bound tail of a batch to the S-free kernel: with the
     hand-off off, at its default and forced from the first streamed iteration on, X and iteration
