@@ -177,6 +177,15 @@ __device__ __forceinline__ GVAE_GLOBAL T *uniform_global(T *p) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
   return (GVAE_GLOBAL T *)(((uintptr_t)hi << 32) | lo);
 }
+template <int V>
+__device__ __forceinline__ typename VecT<V>::type stream_load_g(const GVAE_GLOBAL float *p) {
+  using vec_t = typename VecT<V>::type;
+#if GVAE_STREAM_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const GVAE_GLOBAL vec_t *>(p));
+#else
+  return *reinterpret_cast<const GVAE_GLOBAL vec_t *>(p);
+#endif
+}
 __device__ __forceinline__ f32x4_t stream_load4(const GVAE_GLOBAL float *p) {
 #if GVAE_STREAM_NT
   return __builtin_nontemporal_load(reinterpret_cast<const GVAE_GLOBAL f32x4_t *>(p));
@@ -222,9 +231,16 @@ __device__ __forceinline__ float group_max(float m, int lpr_log2) {
 // count that is not a multiple of 4, which only the public matching entry points produce):
 // one row per group at a time, shape parameters at run time.
 template <int V>
-__device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab, int R, int RS, int a0,
-                                           int Aw, int lpr_log2, const float *Xs, float *T) {
+__device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab_, int R, int RS, int a0,
+                                           int Aw, int lpr_log2, int xs_off, int t_off) {
   using vec_t = typename VecT<V>::type;
+  // (not inlined: device memory and LDS are named as such, and the arguments as wave-uniform;
+  // see as_global)
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  R = uniform(R), RS = uniform(RS), a0 = uniform(a0), Aw = uniform(Aw), lpr_log2 = uniform(lpr_log2);
+  const float *Xs = lds_all + uniform(xs_off);
+  float *T = lds_all + uniform(t_off);
+  const GVAE_GLOBAL float *slab = uniform_global(slab_);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int NR = R * Aw;
   const int cols = RS / V;
@@ -233,7 +249,7 @@ __device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab, int R
   const int rpp = nt >> lpr_log2;       // rows per step of the whole work-group
   for (int row = tid >> lpr_log2; row < NR; row += rpp) {
     const int j = row / Aw, al = row - j * Aw;
-    const float *src = slab + (unsigned)((j * R + a0 + al) * RS);
+    const GVAE_GLOBAL float *src = slab + (unsigned)((j * R + a0 + al) * RS);
     const float *xr = Xs + j * RS;
     float m = -INFINITY;
     for (int c = lr; c < cols; c += 4 * lpr) {
@@ -242,7 +258,7 @@ __device__ __noinline__ void mpm_iter_body(const float *__restrict__ slab, int R
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         cc[u] = min(c + u * lpr, cols - 1) * V;   // past the row end: its last vector again
-        sv[u] = stream_load<V>(src + cc[u]);
+        sv[u] = stream_load_g<V>(src + cc[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -505,7 +521,10 @@ __device__ __forceinline__ void mpm_iter_dispatch(const float *__restrict__ slab
       default: break;
     }
   }
-  mpm_iter_body<V>(slab, R, RS, a0, Aw, lpr_log2, Xs, T);
+  {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    mpm_iter_body<V>(slab, R, RS, a0, Aw, lpr_log2, (int)(Xs - lds_all), (int)(T - lds_all));
+  }
 }
 
 // value of `v` in lane `lane` (a compile-time constant after unrolling) for the whole wavefront
