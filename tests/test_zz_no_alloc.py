@@ -31,7 +31,8 @@ def test_static_scratch_entry_point_equals_workspace_entry_point():
     from graphvae import _hip
     rng = np.random.default_rng(0)
     cases = [([int(r) for r in rng.integers(2, 33, 48)], 32, 50, True),    # first call
-             ([9, 16, 3, 12, 7], 16, 20, False)]                           # second, smaller
+             ([9, 16, 3, 12, 7], 16, 20, False),                           # second, smaller
+             ([104, 77, 20, 5], 104, 6, False)]    # 512-thread work-groups, row maxima bounded in LDS
     for k, (Rh, N, iters, early) in enumerate(cases):
         S, S_off, R = _problem(Rh, N, seed=10 + k)
         X_ws = _hip.x0_uniform(Rh, N, DEV)
